@@ -1,0 +1,136 @@
+/*
+ * mfa.h — C ABI of the MI355X (gfx950) FlashAttention-2 forward hot path.
+ *
+ * This is the drop-in boundary.  Every entry point takes plain pointers, sizes and a raw
+ * hipStream_t (as void*); there is no torch / ATen type anywhere in this file.  The torch
+ * extension `mini_flash_attention._C` (csrc/torch_binding.cpp) is one client, the ctypes
+ * binding used by tests/ is another, and INTEGRATION.md shows the stub a maintainer of the
+ * reference would add to its csrc/mfa/api.cpp.
+ *
+ * What each declaration replaces in the reference (w4096/mini-flash-attention):
+ *
+ *   struct mfa_forward_params                <- struct mfa::ForwardParams      csrc/mfa/flash.h:8-73
+ *   mfa_run_flash_attention_forward()        <- run_flash_attention_forward()  csrc/mfa/flash.h:76, flash.cu:74-82
+ *   mfa_run_flash_attention_with_kv_cache()  <- run_flash_attention_with_kv_cache()
+ *                                                                              csrc/mfa/flash.h:77, flash.cu:85-93
+ *   mfa_forward_params_set_scale()           <- forward_params_init() scale part  csrc/mfa/api.cpp:99-100
+ *   mfa_num_splits_heuristic()               <- num_splits_heuristic() + clamp in forward_params_set_split_kv()
+ *                                                                              csrc/mfa/api.cpp:269-302, 305-327
+ *   mfa_decode_workspace_bytes()             <- workspace sizing in forward_params_set_split_kv()
+ *                                                                              csrc/mfa/api.cpp:332-337
+ *
+ * Conventions (same as the reference): all strides are in ELEMENTS of the tensor's dtype;
+ * q/k/v/o have a unit last-dimension stride; causal masking is TOP-LEFT aligned (key index > query
+ * index is masked, csrc/mfa/prefill.cuh:416-419); inputs are fp16 or bf16, accumulation is fp32.
+ *
+ * All launches are asynchronous on `stream`; inputs are borrowed until the enqueued kernels
+ * finish.  No entry point allocates, frees or synchronises (hipGraph-capturable).
+ * Return value: 0 on success, a negative MFA_ERR_* code otherwise; mfa_last_error() gives the
+ * message for the calling thread.
+ */
+#ifndef MFA_H_
+#define MFA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFA_ABI_VERSION 1
+
+enum {
+    MFA_OK = 0,
+    MFA_ERR_INVALID_ARGUMENT = -1, /* shape / stride / alignment / dtype precondition violated */
+    MFA_ERR_UNSUPPORTED = -2,      /* head_dim or group size outside the compiled set           */
+    MFA_ERR_LAUNCH = -3,           /* HIP reported a launch error                               */
+    MFA_ERR_WORKSPACE = -4         /* split decode requested without oaccum / lseaccum buffers  */
+};
+
+/* Mirrors mfa::ForwardParams (csrc/mfa/flash.h:8-73) field for field, plus three additive
+ * fields at the end that the reference leaves implicit (total_k, num_cus, reserved). */
+typedef struct mfa_forward_params {
+    const void* q_ptr; /* (B,Sq,H,D) or varlen (total_q,H,D)                                   */
+    const void* k_ptr; /* (B,Sk,Hkv,D), varlen (total_k,Hkv,D) or paged (nblk,page,Hkv,D)     */
+    const void* v_ptr;
+    void* o_ptr; /* same layout as q                                                          */
+
+    int64_t q_batch_stride, q_head_stride, q_row_stride;
+    int64_t k_batch_stride, k_head_stride, k_row_stride;
+    int64_t v_batch_stride, v_head_stride, v_row_stride;
+    int64_t o_batch_stride, o_head_stride, o_row_stride;
+
+    int32_t is_causal;
+    int32_t window_size_left;  /* accepted, normalised, unused (api.cpp:88-96)                 */
+    int32_t window_size_right;
+
+    int32_t heads;
+    int32_t kv_heads;
+    int32_t kv_group_size; /* heads / kv_heads                                                 */
+
+    int32_t batch;
+    int32_t seqlen_q; /* dense: Sq; varlen: max_seqlen_q                                       */
+    int32_t seqlen_k; /* dense: Sk; varlen: max_seqlen_k; paged decode: max_blocks*page        */
+
+    int32_t head_dim;
+    float softmax_scale;      /* 1/sqrt(D)                                                     */
+    float softmax_scale_log2; /* softmax_scale * log2(e)                                       */
+
+    int32_t is_bf16; /* 0 = fp16, 1 = bf16                                                     */
+
+    const int32_t* cu_seqlens_q; /* (B+1) or NULL                                              */
+    const int32_t* cu_seqlens_k; /* (B+1) or NULL                                              */
+
+    const int32_t* block_table; /* (B, max_blocks) or NULL                                     */
+    int64_t block_table_batch_stride;
+    int32_t page_block_size;
+    int64_t k_cache_block_stride; /* elements between pages                                    */
+    int64_t v_cache_block_stride;
+
+    const int32_t* seqlens_k; /* decode: (B) valid cache length, NULL = seqlen_k for every b    */
+
+    int32_t num_splits; /* decode: <1 = choose (mfa_num_splits_heuristic), 1 = no split        */
+
+    float* softmax_lse_ptr;      /* decode: (B,H) fp32, natural-log LSE; may be NULL           */
+    float* softmax_lseaccum_ptr; /* decode split: (S,B,H) fp32 workspace                       */
+    float* oaccum_ptr;           /* decode split: (S,B,H,D) fp32 workspace                     */
+
+    /* additive fields */
+    int32_t max_blocks_per_seq; /* paged: columns of block_table (bounds the table reads)      */
+    int32_t num_cus;            /* 0 = query the device                                        */
+    int32_t reserved;
+} mfa_forward_params;
+
+/* ABI / build identification. */
+int mfa_abi_version(void);
+const char* mfa_version(void);
+const char* mfa_last_error(void);
+
+/* softmax_scale = 1/sqrt(head_dim), softmax_scale_log2 = softmax_scale*log2(e); kv_group_size. */
+void mfa_forward_params_set_scale(mfa_forward_params* p);
+
+/* Prefill / varlen / paged-prefill forward: O = softmax(scale*Q K^T + mask) V. */
+int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_stream);
+
+/* Decode (seqlen_q == 1) forward with optional split-KV + LSE combine.
+ * p->num_splits must already be resolved (>= 1); workspaces must be present when it is > 1. */
+int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream);
+
+/* Split count the decode path would choose for this problem on a device with `num_cus` CUs
+ * (0 = query the current device).  `requested` < 1 means "auto"; an explicit request is only
+ * clamped to the number of 64-key tiles, as the reference does (api.cpp:325-327). */
+int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_k, int num_cus);
+
+/* Bytes of fp32 workspace needed for `num_splits`: *oaccum_bytes for (S,B,H,D) and *lse_bytes
+ * for (S,B,H).  Both are 0 when num_splits <= 1. */
+void mfa_decode_workspace_bytes(int num_splits, int batch, int heads, int head_dim,
+                                size_t* oaccum_bytes, size_t* lse_bytes);
+
+/* Number of compute units of HIP device `device` (-1 = current); <0 on error. */
+int mfa_device_cu_count(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFA_H_ */

@@ -1,0 +1,150 @@
+// C ABI of the hot path (declared in include/mfa.h): argument checking, split-count choice and the two
+// launch entry points.  No torch types; compiled into libmfa_hip.so together with the kernels.
+//
+// Error behaviour mirrors the reference's host layer (csrc/mfa/api.cpp): every precondition that
+// api.cpp checks with TORCH_CHECK is a MFA_ERR_INVALID_ARGUMENT here, plus the ones the reference
+// leaves unchecked although its kernels rely on them (16-byte alignment of pointers/strides for the
+// 128-bit accesses, supported head dims, workspaces for split decode).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+
+#include "mfa_launch.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_common(const mfa_forward_params* p) {
+    if (!p) return fail(MFA_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (!p->q_ptr || !p->k_ptr || !p->v_ptr || !p->o_ptr)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "q, k, v and o pointers must be non-NULL");
+    if (p->batch < 0 || p->heads <= 0 || p->kv_heads <= 0 || p->seqlen_q < 0 || p->seqlen_k < 0)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "negative or zero size");
+    if (p->head_dim <= 0 || p->head_dim > 256)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "head dimension must be less than or equal to 256");
+    if (p->heads % p->kv_heads != 0)
+        return fail(MFA_ERR_INVALID_ARGUMENT,
+                    "number of key/value heads must be divisible by number of query heads");
+    if (p->head_dim % 8 != 0)
+        return fail(MFA_ERR_UNSUPPORTED, "head_dim must be a multiple of 8 (got %d)", p->head_dim);
+    if (!aligned16(p->q_ptr) || !aligned16(p->k_ptr) || !aligned16(p->v_ptr) || !aligned16(p->o_ptr))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "q, k, v, o must be 16-byte aligned");
+    const int64_t strides[] = {p->q_batch_stride, p->q_head_stride, p->q_row_stride, p->k_batch_stride,
+                               p->k_head_stride,  p->k_row_stride,  p->v_batch_stride, p->v_head_stride,
+                               p->v_row_stride,   p->o_batch_stride, p->o_head_stride, p->o_row_stride,
+                               p->k_cache_block_stride, p->v_cache_block_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0)
+            return fail(MFA_ERR_INVALID_ARGUMENT, "every q/k/v/o stride must be a multiple of 8 elements (16 bytes)");
+    if (p->block_table) {
+        if (p->page_block_size <= 0) return fail(MFA_ERR_INVALID_ARGUMENT, "page_block_size must be positive");
+        if (p->max_blocks_per_seq <= 0)
+            return fail(MFA_ERR_INVALID_ARGUMENT, "max_blocks_per_seq must be set with a block_table");
+    }
+    return MFA_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int mfa_abi_version(void) { return MFA_ABI_VERSION; }
+
+const char* mfa_version(void) { return "mini-flash-attention gfx950 0.1.0"; }
+
+const char* mfa_last_error(void) { return g_err; }
+
+void mfa_forward_params_set_scale(mfa_forward_params* p) {
+    if (!p || p->head_dim <= 0) return;
+    // reference: csrc/mfa/api.cpp:84, 99-100
+    p->kv_group_size = p->kv_heads > 0 ? p->heads / p->kv_heads : 0;
+    p->softmax_scale = 1.0f / std::sqrt(static_cast<float>(p->head_dim));
+    p->softmax_scale_log2 = static_cast<float>(p->softmax_scale * 1.4426950408889634074);
+}
+
+int mfa_device_cu_count(int device) {
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(MFA_ERR_LAUNCH, "hipGetDevice failed");
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess)
+        return fail(MFA_ERR_LAUNCH, "hipDeviceGetAttribute failed");
+    return n;
+}
+
+// The reference sizes its split count from batch*QUERY heads on 2*SMs (api.cpp:269-302).  The native
+// kernel runs one workgroup per (batch, KV head, split), so the count is re-derived from batch*kv_heads:
+// aim at ~4 workgroups of 256 threads per CU, never cut a split below 4 tiles of 64 keys, and keep the
+// splits even.  Only the ARGUMENT semantics are the reference's: <1 = auto, explicit values are clamped
+// to the number of 64-key tiles (api.cpp:320-327).
+int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_k, int num_cus) {
+    const int ntiles = (seqlen_k + 63) / 64;
+    if (ntiles <= 1) return 1;
+    if (requested >= 1) return requested > ntiles ? ntiles : requested;
+    if (num_cus <= 0) {
+        num_cus = mfa_device_cu_count(-1);
+        if (num_cus <= 0) num_cus = 256;
+    }
+    const long base = static_cast<long>(batch) * kv_heads;
+    if (base <= 0) return 1;
+    const long target = 4L * num_cus;
+    if (base >= target) return 1;
+    long splits = (target + base - 1) / base;
+    const long max_splits = ntiles / 4 > 1 ? ntiles / 4 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 128) splits = 128;
+    if (splits <= 1) return 1;
+    const long per = (ntiles + splits - 1) / splits;
+    splits = (ntiles + per - 1) / per;
+    return static_cast<int>(splits);
+}
+
+void mfa_decode_workspace_bytes(int num_splits, int batch, int heads, int head_dim, size_t* oaccum_bytes,
+                                size_t* lse_bytes) {
+    size_t o = 0, l = 0;
+    if (num_splits > 1) {
+        l = sizeof(float) * static_cast<size_t>(num_splits) * batch * heads;
+        o = l * head_dim;
+    }
+    if (oaccum_bytes) *oaccum_bytes = o;
+    if (lse_bytes) *lse_bytes = l;
+}
+
+int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_stream) {
+    if (int rc = check_common(p)) return rc;
+    if (p->head_dim % 32 != 0)
+        return fail(MFA_ERR_UNSUPPORTED, "prefill supports head_dim in {32,64,...,256} (got %d)", p->head_dim);
+    if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "cu_seqlens_q and cu_seqlens_k must be given together");
+    if (p->batch == 0 || p->seqlen_q == 0) return MFA_OK;
+    const int rc = mfa::launch_prefill(*p, static_cast<hipStream_t>(hip_stream));
+    if (rc == -2) return fail(MFA_ERR_UNSUPPORTED, "no prefill kernel for head_dim %d", p->head_dim);
+    if (rc) return fail(MFA_ERR_LAUNCH, "prefill launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return MFA_OK;
+}
+
+int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream) {
+    if (int rc = check_common(p)) return rc;
+    if (p->seqlen_q != 1)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "flash decoding expects seqlen_q == 1, got %d", p->seqlen_q);
+    if (p->num_splits > 1 && (!p->softmax_lseaccum_ptr || !p->oaccum_ptr))
+        return fail(MFA_ERR_WORKSPACE, "num_splits=%d needs softmax_lseaccum_ptr and oaccum_ptr", p->num_splits);
+    // O may be strided: the combine kernel honours o_*_stride (the reference assumes contiguous, decode.cuh:730)
+    if (p->batch == 0) return MFA_OK;
+    const int rc = mfa::launch_decode(*p, static_cast<hipStream_t>(hip_stream));
+    if (rc) return fail(MFA_ERR_LAUNCH, "decode launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return MFA_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,371 @@
+// Flash-decoding (seqlen_q == 1) for gfx950: a vector x matrix path, HBM-bound, no MFMA, no LDS staging.
+//
+// Replaces flash_attention_fwd_split_kv_kernel / _combine_kernel of the reference
+// (csrc/mfa/decode.cuh:524-662, :666-755) with a different decomposition:
+//   * one workgroup per (batch, KV head, split): all G = Hq/Hkv query heads of the KV head are kept in
+//     registers, so every K/V byte is streamed from HBM exactly once (the reference launches one block
+//     per QUERY head and re-streams the KV head G times, flash.cu:45);
+//   * K/V rows go straight from global memory to VGPRs as 16-byte chunks (LPR lanes cover one row of D
+//     elements, a wave-instruction covers 64/LPR rows), two register buffers deep, so each wave keeps
+//     2*UNR KiB in flight; nothing is staged through LDS because nothing is reused;
+//   * every group of LPR lanes owns its keys' online-softmax state (m, l, acc): the main loop has no
+//     traffic between lane groups; the groups of a wave merge by permlane swaps and the 4 waves through
+//     LDS once, after the loop;
+//   * pages are resolved per KEY (block_table lookups one iteration ahead), so any page_block_size is
+//     correct (the reference resolves once per 64-key tile: decode.cuh:50-55).
+// Numerics follow decode.cuh:296-312 (fp32 dot), :367-383 (online softmax in the log2 domain, P kept
+// fp32), :587-661 (merge, LSE = M*scale + ln L), :718-747 (combine, here max-subtracted).
+#include "mfa_device.h"
+#include "mfa_launch.h"
+
+namespace mfa {
+
+struct DecodeArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;      // (B,H) or null
+    float* lse_acc;  // (S,B,H)
+    float* o_acc;    // (S,B,H,D)
+    const int32_t* seqlens_k;
+    const int32_t* block_table;
+    int64_t q_batch_stride, q_head_stride;
+    int64_t o_batch_stride, o_head_stride;
+    int64_t k_batch_stride, k_head_stride, k_row_stride;
+    int64_t v_batch_stride, v_head_stride, v_row_stride;
+    int64_t k_block_stride, v_block_stride, table_batch_stride;
+    int32_t batch, heads, kv_heads, group, head_dim, seqlen_k;
+    int32_t page_size, page_shift; // page_shift >= 0 when page_size is a power of two
+    int32_t max_blocks;
+    int32_t num_splits, nchunks;
+    float scale_log2; // softmax_scale * log2(e)
+};
+
+constexpr int kDecodeThreads = 256;
+constexpr int kDecodeWaves = 4;
+constexpr int kUnroll = 4; // 16-byte loads of K (and of V) per lane per iteration
+
+template <typename T, int LPR, int GT>
+struct DecodeState {
+    float m[GT];      // running max of scaled (log2-domain) scores
+    float l[GT];      // running sum of exp2
+    float acc[GT][8]; // this lane's 8 output columns
+};
+
+template <int N>
+struct RowBuf {
+    u32x4 r[N];
+};
+
+template <typename T, int LPR, int GT>
+__global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const DecodeArgs a) {
+    constexpr int RPL = 64 / LPR;                          // rows per wave-instruction
+    constexpr int TILE = kDecodeWaves * kUnroll * RPL;     // keys per workgroup iteration
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane % LPR; // 16-byte chunk of the row
+    const int lg = lane / LPR;
+    const bool col_ok = c * 8 < a.head_dim;
+
+    const int split = blockIdx.x;
+    const int hk = blockIdx.y / a.nchunks;
+    const int chunk = blockIdx.y % a.nchunks;
+    const int b = blockIdx.z;
+    const int g0 = chunk * GT; // first query head (within the group) of this workgroup
+
+    int len = a.seqlens_k ? a.seqlens_k[b] : a.seqlen_k;
+    len = min(max(len, 0), a.seqlen_k);
+    // split ranges in units of 64-key tiles (decode.cuh:26-30)
+    const int ntiles = (len + 63) >> 6;
+    const int per = (ntiles + a.num_splits - 1) / a.num_splits;
+    const int kbeg = min(split * per, ntiles) << 6;
+    const int kend = min(min((split + 1) * per, ntiles) << 6, len);
+
+    // ---- query fragments: q[g] = 8 elements of this lane's chunk, kept packed -----------------
+    uint32_t qf[GT][4];
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        const int gq = min(g0 + g, a.group - 1);
+        const char* qp = (const char*)a.q + 2 * (b * a.q_batch_stride + (int64_t)(hk * a.group + gq) * a.q_head_stride);
+        u32x4 t = {0, 0, 0, 0};
+        if (col_ok) t = *(const u32x4*)(qp + 16 * c);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qf[g][i] = t[i];
+    }
+
+    DecodeState<T, LPR, GT> st;
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+        st.m[g] = -INFINITY;
+        st.l[g] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) st.acc[g][i] = 0.f;
+    }
+
+    const bool paged = a.block_table != nullptr;
+    const char* kbase = (const char*)a.k + 2 * ((int64_t)hk * a.k_head_stride + (paged ? 0 : b * a.k_batch_stride));
+    const char* vbase = (const char*)a.v + 2 * ((int64_t)hk * a.v_head_stride + (paged ? 0 : b * a.v_batch_stride));
+    const int32_t* table = paged ? a.block_table + b * a.table_batch_stride : nullptr;
+
+    // key handled by (this wave, this lane group) for unroll slot u of the iteration starting at k0
+    auto key_of = [&](int k0, int u) { return k0 + (u * kDecodeWaves + wave) * RPL + lg; };
+
+    // page id (or the key itself when not paged) for the clamped key
+    auto page_lookup = [&](int key) -> int {
+        key = min(key, kend - 1);
+        if (!paged) return key;
+        const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+        return table[min(pg, a.max_blocks - 1)];
+    };
+    auto row_offsets = [&](int key, int pid, int64_t& ko, int64_t& vo) {
+        key = min(key, kend - 1);
+        if (!paged) {
+            ko = (int64_t)key * a.k_row_stride;
+            vo = (int64_t)key * a.v_row_stride;
+        } else {
+            const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key % a.page_size);
+            ko = (int64_t)pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
+            vo = (int64_t)pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
+        }
+    };
+
+    auto load_rows = [&](RowBuf<kUnroll>& kb, RowBuf<kUnroll>& vb, int k0, const int (&pid)[kUnroll]) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            int64_t ko, vo;
+            row_offsets(key_of(k0, u), pid[u], ko, vo);
+            u32x4 z = {0, 0, 0, 0};
+            kb.r[u] = z;
+            vb.r[u] = z;
+            if (col_ok) {
+                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kbase + 2 * ko + 16 * c));
+                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vbase + 2 * vo + 16 * c));
+            }
+        }
+    };
+
+    auto compute = [&](const RowBuf<kUnroll>& kb, const RowBuf<kUnroll>& vb, int k0) {
+        float s[kUnroll][GT];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const bool valid = key_of(k0, u) < kend;
+#pragma unroll
+            for (int g = 0; g < GT; ++g) {
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d = Elem<T>::dot2(qf[g][i], kb.r[u][i], d);
+                d = group_sum<LPR>(d);
+                s[u][g] = valid ? d * a.scale_log2 : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            float mx = st.m[g];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) mx = fmaxf(mx, s[u][g]);
+            const float ms = (mx == -INFINITY) ? 0.f : mx;
+            const float alpha = fast_exp2(st.m[g] - ms);
+            st.m[g] = mx;
+            float p[kUnroll];
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                p[u] = fast_exp2(s[u][g] - ms);
+                ps += p[u];
+            }
+            st.l[g] = st.l[g] * alpha + ps;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a0 = st.acc[g][2 * i] * alpha, a1 = st.acc[g][2 * i + 1] * alpha;
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    a0 = fmaf(p[u], Elem<T>::lo(vb.r[u][i]), a0);
+                    a1 = fmaf(p[u], Elem<T>::hi(vb.r[u][i]), a1);
+                }
+                st.acc[g][2 * i] = a0;
+                st.acc[g][2 * i + 1] = a1;
+            }
+        }
+    };
+
+    if (kbeg < kend) {
+        RowBuf<kUnroll> kA, vA, kB, vB;
+        int pid[kUnroll], pidn[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg, u));
+        load_rows(kA, vA, kbeg, pid);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg + TILE, u));
+        for (int k0 = kbeg; k0 < kend; k0 += 2 * TILE) {
+            const bool has1 = k0 + TILE < kend, has2 = k0 + 2 * TILE < kend;
+            if (has1) load_rows(kB, vB, k0 + TILE, pid);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) pidn[u] = page_lookup(key_of(k0 + 2 * TILE, u));
+            compute(kA, vA, k0);
+            if (has2) load_rows(kA, vA, k0 + 2 * TILE, pidn);
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(k0 + 3 * TILE, u));
+            if (has1) compute(kB, vB, k0 + TILE);
+        }
+    }
+
+    // ---- merge the lane groups of this wave (xor LPR, 2*LPR, ... 32) ---------------------------
+#pragma unroll
+    for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            const float mo = __shfl_xor(st.m[g], off);
+            const float lo = __shfl_xor(st.l[g], off);
+            const float mn = fmaxf(st.m[g], mo);
+            const float ms = (mn == -INFINITY) ? 0.f : mn;
+            const float fa = fast_exp2(st.m[g] - ms), fb = fast_exp2(mo - ms);
+            st.m[g] = mn;
+            st.l[g] = st.l[g] * fa + lo * fb;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float ao = __shfl_xor(st.acc[g][i], off);
+                st.acc[g][i] = st.acc[g][i] * fa + ao * fb;
+            }
+        }
+    }
+
+    // ---- merge the 4 waves through LDS ------------------------------------------------------
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sm_ml = smem;                              // [wave][GT][2]
+    float* sm_acc = smem + kDecodeWaves * GT * 2;     // [wave][GT][LPR*8]
+    if (lane < LPR) {
+#pragma unroll
+        for (int g = 0; g < GT; ++g) {
+            if (lane == 0) {
+                sm_ml[(wave * GT + g) * 2 + 0] = st.m[g];
+                sm_ml[(wave * GT + g) * 2 + 1] = st.l[g];
+            }
+            float* dst = sm_acc + ((wave * GT + g) * LPR + c) * 8;
+            *(f32x4*)(dst) = f32x4{st.acc[g][0], st.acc[g][1], st.acc[g][2], st.acc[g][3]};
+            *(f32x4*)(dst + 4) = f32x4{st.acc[g][4], st.acc[g][5], st.acc[g][6], st.acc[g][7]};
+        }
+    }
+    __syncthreads();
+
+    const int D = a.head_dim;
+    for (int idx = threadIdx.x; idx < GT * D; idx += kDecodeThreads) {
+        const int g = idx / D, d = idx - g * D;
+        if (g0 + g >= a.group) break;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < kDecodeWaves; ++w) M = fmaxf(M, sm_ml[(w * GT + g) * 2]);
+        const float Ms = (M == -INFINITY) ? 0.f : M;
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int w = 0; w < kDecodeWaves; ++w) {
+            const float f = fast_exp2(sm_ml[(w * GT + g) * 2] - Ms);
+            L += sm_ml[(w * GT + g) * 2 + 1] * f;
+            o += sm_acc[(w * GT + g) * LPR * 8 + d] * f;
+        }
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        o *= inv;
+        const int hq = hk * a.group + g0 + g;
+        // natural-log LSE of the scaled scores: M is in the log2 domain
+        const float lse = L > 0.f ? M * 0.6931471805599453f + __logf(L) : -INFINITY;
+        if (a.num_splits > 1) {
+            const int64_t slot = ((int64_t)split * a.batch + b) * a.heads + hq;
+            a.o_acc[slot * D + d] = o;
+            if (d == 0) a.lse_acc[slot] = lse;
+        } else {
+            char* op = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)hq * a.o_head_stride + d);
+            const uint32_t pk = Elem<T>::pack(o, 0.f);
+            *(uint16_t*)op = (uint16_t)pk;
+            if (d == 0 && a.lse) a.lse[(int64_t)b * a.heads + hq] = lse;
+        }
+    }
+}
+
+// O = sum_s o_s * exp(lse_s - LSE), LSE = ln sum_s exp(lse_s)  (decode.cuh:718-747, max-subtracted)
+template <typename T>
+__global__ __launch_bounds__(256) void decode_combine_kernel(const DecodeArgs a) {
+    const int D = a.head_dim;
+    const int64_t BH = (int64_t)a.batch * a.heads;
+    // one (batch, head) row per D-thread slice of the block
+    const int rows_per_block = 256 / min(D, 256);
+    const int64_t bh = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / D;
+    const int d = threadIdx.x % D;
+    if (bh >= BH || threadIdx.x >= rows_per_block * D) return;
+    float M = -INFINITY;
+    for (int s = 0; s < a.num_splits; ++s) M = fmaxf(M, a.lse_acc[s * BH + bh]);
+    float W = 0.f, o = 0.f;
+    if (M != -INFINITY) {
+        for (int s = 0; s < a.num_splits; ++s) {
+            const float w = __expf(a.lse_acc[s * BH + bh] - M);
+            W += w;
+            o += w * a.o_acc[(s * BH + bh) * D + d];
+        }
+        o /= W;
+    }
+    const int b = bh / a.heads, h = bh % a.heads;
+    char* op = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)h * a.o_head_stride + d);
+    *(uint16_t*)op = (uint16_t)Elem<T>::pack(o, 0.f);
+    if (d == 0 && a.lse) a.lse[bh] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
+}
+
+template <typename T, int LPR, int GT>
+static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
+    dim3 grid(a.num_splits, a.kv_heads * a.nchunks, a.batch);
+    const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
+    hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT>), grid, dim3(kDecodeThreads), smem, stream, a);
+    if (a.num_splits > 1) {
+        const int rows_per_block = 256 / a.head_dim > 0 ? 256 / a.head_dim : 1;
+        const int64_t BH = (int64_t)a.batch * a.heads;
+        dim3 cgrid((unsigned)((BH + rows_per_block - 1) / rows_per_block));
+        hipLaunchKernelGGL((decode_combine_kernel<T>), cgrid, dim3(256), 0, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T, int LPR>
+static int launch_decode_g(const DecodeArgs& a, int gt, hipStream_t stream) {
+    switch (gt) {
+    case 1: return launch_decode_t<T, LPR, 1>(a, stream);
+    case 2: return launch_decode_t<T, LPR, 2>(a, stream);
+    case 3: return launch_decode_t<T, LPR, 3>(a, stream);
+    case 4: return launch_decode_t<T, LPR, 4>(a, stream);
+    case 6: return launch_decode_t<T, LPR, 6>(a, stream);
+    default: return launch_decode_t<T, LPR, 8>(a, stream);
+    }
+}
+
+template <typename T>
+static int launch_decode_d(const DecodeArgs& a, int gt, hipStream_t stream) {
+    if (a.head_dim <= 32) return launch_decode_g<T, 4>(a, gt, stream);
+    if (a.head_dim <= 64) return launch_decode_g<T, 8>(a, gt, stream);
+    if (a.head_dim <= 128) return launch_decode_g<T, 16>(a, gt, stream);
+    return launch_decode_g<T, 32>(a, gt, stream);
+}
+
+// Host launcher: picks the group tile GT (query heads per workgroup) and chunks larger groups.
+int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
+    DecodeArgs a{};
+    a.q = p.q_ptr; a.k = p.k_ptr; a.v = p.v_ptr; a.o = p.o_ptr;
+    a.lse = p.softmax_lse_ptr; a.lse_acc = p.softmax_lseaccum_ptr; a.o_acc = p.oaccum_ptr;
+    a.seqlens_k = p.seqlens_k; a.block_table = p.block_table;
+    a.q_batch_stride = p.q_batch_stride; a.q_head_stride = p.q_head_stride;
+    a.o_batch_stride = p.o_batch_stride; a.o_head_stride = p.o_head_stride;
+    a.k_batch_stride = p.k_batch_stride; a.k_head_stride = p.k_head_stride; a.k_row_stride = p.k_row_stride;
+    a.v_batch_stride = p.v_batch_stride; a.v_head_stride = p.v_head_stride; a.v_row_stride = p.v_row_stride;
+    a.k_block_stride = p.k_cache_block_stride; a.v_block_stride = p.v_cache_block_stride;
+    a.table_batch_stride = p.block_table_batch_stride;
+    a.batch = p.batch; a.heads = p.heads; a.kv_heads = p.kv_heads; a.group = p.heads / p.kv_heads;
+    a.head_dim = p.head_dim; a.seqlen_k = p.seqlen_k;
+    a.page_size = p.page_block_size > 0 ? p.page_block_size : 1;
+    a.page_shift = (a.page_size & (a.page_size - 1)) == 0 ? __builtin_ctz(a.page_size) : -1;
+    a.max_blocks = p.max_blocks_per_seq > 0 ? p.max_blocks_per_seq : (p.seqlen_k + a.page_size - 1) / a.page_size;
+    a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
+    a.scale_log2 = p.softmax_scale_log2;
+    const int G = a.group;
+    int gt = G <= 4 ? G : (G <= 6 ? 6 : 8);
+    if (G == 5) gt = 6;
+    a.nchunks = (G + gt - 1) / gt;
+    return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
+}
+
+} // namespace mfa

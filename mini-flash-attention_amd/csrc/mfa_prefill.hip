@@ -1,0 +1,406 @@
+// FlashAttention-2 forward (prefill / varlen / paged prefill) for gfx950, fp16/bf16 MFMA, wave64.
+//
+// Replaces flash_attention_fwd_kernel of the reference (csrc/mfa/prefill.cuh:712-803).  Same math
+// (Appendix A of SURVEY.md: raw-score running max, exp2 with scale*log2e folded in, fp32 row sums of
+// un-rounded P, P rounded to the element type before P.V, fp32 O, 1/l at the end with a 0/NaN guard,
+// TOP-LEFT causal mask prefill.cuh:416-419) on a CDNA4-shaped decomposition:
+//
+//   * workgroup = NW waves, each wave owns 32 query rows (BM = 32*NW); key tile BN = 64;
+//   * "swapped" first product  S^T = K . Q^T  with v_mfma_f32_32x32x16: the 32x32 accumulator has the
+//     QUERY ROW on the lane and 16 keys in its registers, so row max / row sum are in-lane plus one
+//     exchange with lane^32, and no score ever crosses lanes through LDS;
+//   * the accumulator is converted in place to 16-bit and used directly as the B operand of the second
+//     product  O^T = V^T . P^T  (k-order inside a step is permuted: row 16s + 8(j>>2) + 4h + (j&3));
+//     V^T fragments with that same order come from ds_read_b64_tr_b16 transposed LDS reads;
+//   * K and V tiles are staged global -> registers -> LDS (issue early, write late), double-buffered,
+//     ONE barrier per key tile; K rows are XOR-swizzled per 16-byte chunk for conflict-free
+//     ds_read_b128, V rows per 64-byte unit for conflict-free transposed reads;
+//   * O leaves through LDS as whole rows (16-byte coalesced stores);
+//   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
+//     run on one XCD (shared L2), heaviest causal blocks first.
+#include "mfa_device.h"
+#include "mfa_launch.h"
+
+namespace mfa {
+
+struct PrefillArgs {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    const int32_t* cu_q;
+    const int32_t* cu_k;
+    const int32_t* block_table;
+    int64_t q_batch_stride, q_head_stride, q_row_stride;
+    int64_t k_batch_stride, k_head_stride, k_row_stride;
+    int64_t v_batch_stride, v_head_stride, v_row_stride;
+    int64_t o_batch_stride, o_head_stride, o_row_stride;
+    int64_t k_block_stride, v_block_stride, table_batch_stride;
+    int32_t batch, heads, kv_heads, group, head_dim;
+    int32_t seqlen_q, seqlen_k; // dense lengths, or max lengths when varlen
+    int32_t page_size, page_shift, max_blocks;
+    int32_t num_m_blocks;
+    int32_t total_blocks;
+    int32_t is_causal;
+    float scale_log2;
+};
+
+constexpr int kBN = 64; // keys per tile
+
+// LDS row pitch in bytes for a head dim (rows padded to a power of two >= 64 B)
+template <int D>
+struct Pitch {
+    static constexpr int RB = D <= 32 ? 64 : D <= 64 ? 128 : D <= 128 ? 256 : 512;
+};
+
+// 16-byte-chunk XOR for the K image (rows read by ds_read_b128, 16 lanes = 16 different rows)
+template <int RB>
+__device__ __forceinline__ int k_swz(int row) {
+    if constexpr (RB == 64) return (row >> 2) & 3;
+    else if constexpr (RB == 128) return (row >> 1) & 7;
+    else return row & 15;
+}
+// 64-byte-unit XOR for the V image (transposed reads take 4 consecutive keys x 64 B per half-wave)
+template <int RB>
+__device__ __forceinline__ int v_swz(int row) {
+    if constexpr (RB == 64) return 0;
+    else if constexpr (RB == 128) return (row >> 1) & 1;
+    else return row & 3;
+}
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs a) {
+    using E = Elem<T>;
+    using frag8 = typename E::frag8;
+    constexpr int RB = Pitch<D>::RB;
+    constexpr int NT = 64 * NW;
+    constexpr int BM = 32 * NW;
+    constexpr int KS = D / 16;   // k-steps of the first product
+    constexpr int DB = D / 32;   // 32-wide output column blocks of the second product
+    constexpr int CH = D / 8;    // 16-byte chunks per row
+    constexpr int TILE_CHUNKS = kBN * CH;
+    constexpr int CPT = (TILE_CHUNKS + NT - 1) / NT; // chunks per thread per tile (K, and V)
+    constexpr int TILE_BYTES = kBN * RB;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const sK = smem;                  // [2][64][RB]
+    char* const sV = smem + 2 * TILE_BYTES; // [2][64][RB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+
+    // ---- workgroup -> (batch, head, query block): XCD-aware, bijective ---------------------------
+    int vid;
+    {
+        const int bid = blockIdx.x, n = a.total_blocks;
+        const int q8 = n >> 3, r8 = n & 7, x = bid & 7;
+        vid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
+    }
+    const int nmb = a.num_m_blocks;
+    int mblk = vid % nmb;
+    const int bh = vid / nmb;
+    const int hq = bh % a.heads;
+    const int b = bh / a.heads;
+    const int hk = hq / a.group;
+    mblk = nmb - 1 - mblk; // heaviest causal blocks first
+
+    int sq, sk;
+    int64_t q_off, o_off, k_off, v_off;
+    if (a.cu_q) {
+        const int q0 = a.cu_q[b], k0 = a.cu_k[b];
+        sq = a.cu_q[b + 1] - q0;
+        sk = a.cu_k[b + 1] - k0;
+        q_off = (int64_t)q0 * a.q_row_stride;
+        o_off = (int64_t)q0 * a.o_row_stride;
+        k_off = a.block_table ? 0 : (int64_t)k0 * a.k_row_stride;
+        v_off = a.block_table ? 0 : (int64_t)k0 * a.v_row_stride;
+    } else {
+        sq = a.seqlen_q;
+        sk = a.seqlen_k;
+        q_off = b * a.q_batch_stride;
+        o_off = b * a.o_batch_stride;
+        k_off = a.block_table ? 0 : b * a.k_batch_stride;
+        v_off = a.block_table ? 0 : b * a.v_batch_stride;
+    }
+    const int m0 = mblk * BM;
+    if (m0 >= sq) return; // whole workgroup, before any barrier
+
+    const char* qbase = (const char*)a.q + 2 * (q_off + (int64_t)hq * a.q_head_stride);
+    const char* kbase = (const char*)a.k + 2 * (k_off + (int64_t)hk * a.k_head_stride);
+    const char* vbase = (const char*)a.v + 2 * (v_off + (int64_t)hk * a.v_head_stride);
+    char* obase = (char*)a.o + 2 * (o_off + (int64_t)hq * a.o_head_stride);
+    const int32_t* table = a.block_table ? a.block_table + b * a.table_batch_stride : nullptr;
+
+    // key tiles this workgroup visits (causal range clamped to the key length)
+    int nt = (sk + kBN - 1) / kBN;
+    if (a.is_causal) nt = min(nt, (min(m0 + BM, sq) + kBN - 1) / kBN);
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): row m0+32*wave+r, columns 16*ks + 8h .. +7 -------
+    const int qrow = m0 + 32 * wave + r;
+    frag8 qf[KS];
+    {
+        const char* qp = qbase + 2 * ((int64_t)min(qrow, sq - 1) * a.q_row_stride) + 16 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const frag8*)(qp + 32 * ks);
+    }
+
+    // ---- staging: thread t moves chunk (t + i*NT) of the tile: row = idx / CH, ch = idx % CH ------
+    u32x4 kst[CPT], vst[CPT];
+    auto stage_load = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int idx = tid + i * NT;
+            const int row = idx / CH, ch = idx - row * CH;
+            const int key = j * kBN + row;
+            u32x4 z = {0, 0, 0, 0};
+            kst[i] = z;
+            vst[i] = z;
+            if ((TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) && key < sk) {
+                int64_t ko, vo;
+                if (table) {
+                    const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+                    const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
+                    const int64_t pid = table[min(pg, a.max_blocks - 1)];
+                    ko = pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
+                    vo = pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
+                } else {
+                    ko = (int64_t)key * a.k_row_stride;
+                    vo = (int64_t)key * a.v_row_stride;
+                }
+                kst[i] = *(const u32x4*)(kbase + 2 * ko + 16 * ch);
+                vst[i] = *(const u32x4*)(vbase + 2 * vo + 16 * ch);
+            }
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int idx = tid + i * NT;
+            if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
+                const int row = idx / CH, ch = idx - row * CH;
+                const int kch = ch ^ k_swz<RB>(row);
+                const int vch = (((ch >> 2) ^ v_swz<RB>(row)) << 2) | (ch & 3);
+                *(u32x4*)(sK + buf * TILE_BYTES + row * RB + 16 * kch) = kst[i];
+                *(u32x4*)(sV + buf * TILE_BYTES + row * RB + 16 * vch) = vst[i];
+            }
+        }
+    };
+
+    // ---- per-lane LDS read addresses -----------------------------------------------------------
+    // K fragment (A operand): row 32*kb + r, chunk 2*ks + h  ->  16*((2*ks) ^ (swz ^ h))
+    const int k_xh = k_swz<RB>(r) ^ h;
+    const int k_row_off = r * RB;
+    // V^T fragment via transposed read: 16-lane group g16 = lane>>4 : h = g16>>1, column half = g16&1;
+    // lane 4q+p of the group addresses key 16*s + 4h + q (+8 for the second read), columns 4p..4p+3 of
+    // the 16-column half, i.e. byte (32*db + 16*(g16&1) + 4p)*2 of the row.
+    const int tq = (lane >> 2) & 3, tp = lane & 3, tcol = (lane >> 4) & 1;
+    const int v_key0 = 4 * h + tq;                        // + 16*s (+8)
+    const int v_in64 = (2 * tcol + (tp >> 1)) * 16 + (tp & 1) * 8; // byte inside the 64-byte unit
+    // v_swz(row) depends on key&3 (= tq, RB>=256) or (key>>1)&1 (RB==128); +8/+16*s leave both unchanged
+    const int v_x = v_swz<RB>(v_key0);
+
+    float m_run = -INFINITY; // running max of RAW scores (prefill.cuh:454-462)
+    float l_run = 0.f;       // this lane's partial row sum (its 32 keys of every tile)
+    f32x16 oacc[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) oacc[d][i] = 0.f;
+
+    const float c = a.scale_log2;
+    const int wrow0 = m0 + 32 * wave; // first query row of this wave
+
+    if (nt > 0) {
+        stage_load(0);
+        stage_write(0);
+    }
+    __syncthreads();
+
+    for (int j = 0; j < nt; ++j) {
+        const int cur = j & 1;
+        const bool more = j + 1 < nt;
+        if (more) stage_load(j + 1);
+
+        // a wave whose rows all precede this tile's first key has nothing to do under the causal mask
+        const bool active = !a.is_causal || j * kBN <= wrow0 + 31;
+        if (active) {
+            const char* kt = sK + cur * TILE_BYTES;
+            const char* vt = sV + cur * TILE_BYTES;
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const frag8 kf = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * ks) ^ k_xh));
+                    s[kb] = E::mfma32(kf, qf[ks], s[kb]);
+                }
+            }
+            // mask: key > query row (top-left causal) or key >= sk
+            const bool need_mask = (a.is_causal && j * kBN + kBN - 1 > wrow0) || (j + 1) * kBN > sk;
+            if (need_mask) {
+                const int lim = a.is_causal ? min(qrow, sk - 1) : sk - 1; // keys <= lim stay
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int key = j * kBN + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (key > lim) s[kb][i] = -INFINITY;
+                    }
+            }
+            // ---- online softmax, all in this lane's registers ---------------------------------------
+            float mt = s[0][0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[kb][i]);
+            mt = fmaxf(mt, swap32(mt));
+            const float m_new = fmaxf(m_run, mt);
+            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = fast_exp2((m_run - ms) * c);
+            const float mc = ms * c;
+            m_run = m_new;
+            float psum = 0.f;
+            uint32_t pk[2][8];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float p0 = fast_exp2(fmaf(s[kb][2 * i], c, -mc));
+                    const float p1 = fast_exp2(fmaf(s[kb][2 * i + 1], c, -mc));
+                    psum += p0 + p1;
+                    pk[kb][i] = E::pack(p0, p1);
+                }
+            l_run = l_run * alpha + psum;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+
+            // ---- O^T += V^T . P^T : 4 k-steps of 16 keys x DB column blocks ---------------------------
+#pragma unroll
+            for (int s16 = 0; s16 < 4; ++s16) {
+                const int kb = s16 >> 1, sh = s16 & 1;
+                u32x4 pw = {pk[kb][4 * sh], pk[kb][4 * sh + 1], pk[kb][4 * sh + 2], pk[kb][4 * sh + 3]};
+                const frag8 pf = __builtin_bit_cast(frag8, pw);
+                const char* vrow = vt + (16 * s16 + v_key0) * RB + v_in64;
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int unit = (d ^ v_x) * 64;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + unit));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + 8 * RB + unit));
+                    typedef short s16x8 __attribute__((ext_vector_type(8)));
+                    const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
+                }
+            }
+        }
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
+    const float l_tot = l_run + swap32(l_run);
+    const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    // the loop's last barrier guarantees every wave is done with the K/V buffers
+    char* so = smem + wave * 32 * RB; // this wave's 32 rows x RB bytes
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            // registers 4*g4..4*g4+3 are columns 32*d + 8*g4 + 4*h + 0..3 of row r
+            u32x2 w;
+            w[0] = E::pack(oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv);
+            w[1] = E::pack(oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv);
+            const int ch = 4 * d + g4;
+            *(u32x2*)(so + r * RB + 16 * (ch ^ k_swz<RB>(r)) + 8 * h) = w;
+        }
+    // same wave wrote and reads: LDS ops of one wave complete in order
+    constexpr int ROWS_PER_IT = 64 / CH > 0 ? 64 / CH : 1;
+    if constexpr (64 % CH == 0) {
+        const int rr0 = lane / CH, ch = lane % CH;
+#pragma unroll
+        for (int it = 0; it < 32 / ROWS_PER_IT; ++it) {
+            const int rr = it * ROWS_PER_IT + rr0;
+            const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
+            const int grow = wrow0 + rr;
+            if (grow < sq) *(u32x4*)(obase + 2 * ((int64_t)grow * a.o_row_stride) + 16 * ch) = val;
+        }
+    } else {
+        // CH does not divide 64 (D = 96, 160, ...): walk the 32*CH chunks of the wave linearly
+        for (int idx = lane; idx < 32 * CH; idx += 64) {
+            const int rr = idx / CH, ch = idx - rr * CH;
+            const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
+            const int grow = wrow0 + rr;
+            if (grow < sq) *(u32x4*)(obase + 2 * ((int64_t)grow * a.o_row_stride) + 16 * ch) = val;
+        }
+    }
+}
+
+template <typename T, int D, int NW>
+static int launch_prefill_t(PrefillArgs& a, hipStream_t stream) {
+    constexpr int BM = 32 * NW;
+    constexpr int RB = Pitch<D>::RB;
+    constexpr size_t smem = 4 * kBN * RB;
+    a.num_m_blocks = (a.seqlen_q + BM - 1) / BM;
+    const int64_t total = (int64_t)a.num_m_blocks * a.heads * a.batch;
+    if (total <= 0) return 0;
+    if (total > 0x7fffffffLL) return -1;
+    a.total_blocks = (int)total;
+    auto kern = prefill_fwd_kernel<T, D, NW>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (smem > 64 * 1024) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
+                hipSuccess)
+                return -3;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * NW), smem, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T>
+static int launch_prefill_d(PrefillArgs& a, hipStream_t stream) {
+    switch (a.head_dim) {
+    case 32: return launch_prefill_t<T, 32, 4>(a, stream);
+    case 64: return launch_prefill_t<T, 64, 4>(a, stream);
+    case 96: return launch_prefill_t<T, 96, 4>(a, stream);
+    case 128: return launch_prefill_t<T, 128, 4>(a, stream);
+    case 160: return launch_prefill_t<T, 160, 4>(a, stream);
+    case 192: return launch_prefill_t<T, 192, 4>(a, stream);
+    case 224: return launch_prefill_t<T, 224, 4>(a, stream);
+    case 256: return launch_prefill_t<T, 256, 4>(a, stream);
+    default: return -2;
+    }
+}
+
+int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
+    PrefillArgs a{};
+    a.q = p.q_ptr; a.k = p.k_ptr; a.v = p.v_ptr; a.o = p.o_ptr;
+    a.cu_q = p.cu_seqlens_q; a.cu_k = p.cu_seqlens_k; a.block_table = p.block_table;
+    a.q_batch_stride = p.q_batch_stride; a.q_head_stride = p.q_head_stride; a.q_row_stride = p.q_row_stride;
+    a.k_batch_stride = p.k_batch_stride; a.k_head_stride = p.k_head_stride; a.k_row_stride = p.k_row_stride;
+    a.v_batch_stride = p.v_batch_stride; a.v_head_stride = p.v_head_stride; a.v_row_stride = p.v_row_stride;
+    a.o_batch_stride = p.o_batch_stride; a.o_head_stride = p.o_head_stride; a.o_row_stride = p.o_row_stride;
+    a.k_block_stride = p.k_cache_block_stride; a.v_block_stride = p.v_cache_block_stride;
+    a.table_batch_stride = p.block_table_batch_stride;
+    a.batch = p.batch; a.heads = p.heads; a.kv_heads = p.kv_heads; a.group = p.heads / p.kv_heads;
+    a.head_dim = p.head_dim; a.seqlen_q = p.seqlen_q; a.seqlen_k = p.seqlen_k;
+    a.page_size = p.page_block_size > 0 ? p.page_block_size : 1;
+    a.page_shift = (a.page_size & (a.page_size - 1)) == 0 ? __builtin_ctz(a.page_size) : -1;
+    a.max_blocks = p.max_blocks_per_seq > 0 ? p.max_blocks_per_seq : 0x7fffffff;
+    a.is_causal = p.is_causal;
+    a.scale_log2 = p.softmax_scale_log2;
+    return p.is_bf16 ? launch_prefill_d<BFloat>(a, stream) : launch_prefill_d<Half>(a, stream);
+}
+
+} // namespace mfa

@@ -1,0 +1,270 @@
+// mini_flash_attention._C — the PyTorch-ROCm extension module with the reference's ABI:
+//   mini_flash_attention_forward / _varlen_forward / _with_kvcache     (reference csrc/api.cpp:4-9)
+// Host op layer = the reference's csrc/mfa/api.cpp re-done above the C ABI of include/mfa.h: validate,
+// allocate the output (and split workspaces) from the caching allocator, fill mfa_forward_params, launch
+// on the current HIP stream.  This file is the ONLY torch-aware native code; it never computes.
+#include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/extension.h>
+
+#include <optional>
+
+#include "mfa.h"
+
+namespace {
+
+#define MFA_CHECK_DEVICE(x) TORCH_CHECK(x.is_cuda(), #x " must be on CUDA")
+#define MFA_CHECK_SHAPE(x, ...) \
+    TORCH_CHECK(x.sizes() == at::IntArrayRef({__VA_ARGS__}), #x " must have shape (" #__VA_ARGS__ ")")
+
+void* current_stream(const at::Tensor& t) {
+    return static_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
+
+void check_rc(int rc) { TORCH_CHECK(rc == MFA_OK, "mini_flash_attention: ", mfa_last_error(), " (code ", rc, ")"); }
+
+void check_dtypes(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v) {
+    auto dtype = q.scalar_type();
+    TORCH_CHECK(dtype == at::kHalf || dtype == at::kBFloat16, "FlashAttention only support fp16 and bf16 data type");
+    TORCH_CHECK(k.scalar_type() == dtype, "query and key must have the same dtype");
+    TORCH_CHECK(v.scalar_type() == dtype, "query and value must have the same dtype");
+    MFA_CHECK_DEVICE(q);
+    MFA_CHECK_DEVICE(k);
+    MFA_CHECK_DEVICE(v);
+    TORCH_CHECK(q.stride(-1) == 1, "Input tensor must have contiguous last dimension");
+    TORCH_CHECK(k.stride(-1) == 1, "Input tensor must have contiguous last dimension");
+    TORCH_CHECK(v.stride(-1) == 1, "Input tensor must have contiguous last dimension");
+}
+
+// strides as the reference takes them (api.cpp:58-74): row = stride(-3), head = stride(-2), batch = stride(0)
+void set_tensor_strides(mfa_forward_params& p, const at::Tensor& q, const at::Tensor& k, const at::Tensor& v,
+                        const at::Tensor& o, bool has_batch_dim) {
+    p.q_ptr = q.data_ptr();
+    p.k_ptr = k.data_ptr();
+    p.v_ptr = v.data_ptr();
+    p.o_ptr = o.data_ptr();
+    p.q_row_stride = q.stride(-3);
+    p.k_row_stride = k.stride(-3);
+    p.v_row_stride = v.stride(-3);
+    p.o_row_stride = o.stride(-3);
+    p.q_head_stride = q.stride(-2);
+    p.k_head_stride = k.stride(-2);
+    p.v_head_stride = v.stride(-2);
+    p.o_head_stride = o.stride(-2);
+    if (has_batch_dim) {
+        p.q_batch_stride = q.stride(0);
+        p.k_batch_stride = k.stride(0);
+        p.v_batch_stride = v.stride(0);
+        p.o_batch_stride = o.stride(0);
+    }
+    p.is_bf16 = q.scalar_type() == at::kBFloat16;
+}
+
+void set_windows(mfa_forward_params& p, int wl, int wr, int seqlen_k) {
+    // api.cpp:88-96: accepted and normalised, only is_causal has an effect
+    p.is_causal = wl < 0 && wr == 0;
+    if (wl < 0 && wr >= 0) wl = seqlen_k;
+    if (wl >= 0 && wr < 0) wr = seqlen_k;
+    p.window_size_left = wl;
+    p.window_size_right = wr;
+}
+
+void set_paged(mfa_forward_params& p, const at::Tensor& block_table, const at::Tensor& k, const at::Tensor& v,
+               int batch) {
+    MFA_CHECK_DEVICE(block_table);
+    TORCH_CHECK(block_table.scalar_type() == at::kInt, "block_table must be int32");
+    TORCH_CHECK(block_table.dim() == 2 && block_table.size(0) == batch,
+                "block_table must have the same batch size as q");
+    TORCH_CHECK(block_table.stride(-1) == 1, "block_table must have contiguous last dimension");
+    p.block_table = block_table.data_ptr<int>();
+    p.block_table_batch_stride = block_table.stride(0);
+    p.max_blocks_per_seq = block_table.size(1);
+    p.page_block_size = k.size(1);
+    p.k_cache_block_stride = k.stride(0);
+    p.v_cache_block_stride = v.stride(0);
+}
+
+// reference: mfa::flash_attention_forward, csrc/mfa/api.cpp:113-186
+at::Tensor flash_attention_forward(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v,
+                                   std::optional<at::Tensor> out_, bool is_causal, int window_size_left,
+                                   int window_size_right) {
+    check_dtypes(q, k, v);
+    c10::DeviceGuard guard(q.device());
+    TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be 4-D (batch, seqlen, heads, head_dim)");
+    const int batch = q.size(0), seqlen_q = q.size(1), num_heads = q.size(2), head_dim = q.size(3);
+    const int seqlen_k = k.size(1), kv_num_heads = k.size(2);
+    TORCH_CHECK(k.size(0) == batch, "batch size of q and k must be the same");
+    TORCH_CHECK(v.size(0) == batch, "batch size of q and v must be the same");
+    TORCH_CHECK(v.size(1) == seqlen_k, "sequence length of k must be the same as v");
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    if (window_size_left >= seqlen_k) window_size_left = -1;
+    if (window_size_right >= seqlen_k) window_size_right = -1;
+    if (is_causal) window_size_right = 0;
+    MFA_CHECK_SHAPE(q, batch, seqlen_q, num_heads, head_dim);
+    MFA_CHECK_SHAPE(k, batch, seqlen_k, kv_num_heads, head_dim);
+    MFA_CHECK_SHAPE(v, batch, seqlen_k, kv_num_heads, head_dim);
+
+    at::Tensor out;
+    if (out_.has_value()) {
+        out = out_.value();
+        TORCH_CHECK(out.scalar_type() == q.scalar_type(), "Output tensor must have the dtype of q");
+        MFA_CHECK_DEVICE(out);
+        TORCH_CHECK(out.stride(-1) == 1, "Output tensor must have contiguous last dimension");
+        MFA_CHECK_SHAPE(out, batch, seqlen_q, num_heads, head_dim);
+    } else {
+        out = at::empty_like(q);
+    }
+
+    mfa_forward_params p{};
+    set_tensor_strides(p, q, k, v, out, true);
+    p.batch = batch;
+    p.seqlen_q = seqlen_q;
+    p.seqlen_k = seqlen_k;
+    p.heads = num_heads;
+    p.kv_heads = kv_num_heads;
+    p.head_dim = head_dim;
+    mfa_forward_params_set_scale(&p);
+    set_windows(p, window_size_left, window_size_right, seqlen_k);
+    check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
+    return out;
+}
+
+// reference: mfa::flash_attention_varlen_forward, csrc/mfa/api.cpp:189-267
+at::Tensor flash_attention_varlen_forward(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v,
+                                          const at::Tensor& cu_seqlens_q, const at::Tensor& cu_seqlens_k,
+                                          const int max_seqlen_q, const int max_seqlen_k, bool is_causal,
+                                          int window_size_left, int window_size_right,
+                                          const std::optional<at::Tensor>& block_table_) {
+    check_dtypes(q, k, v);
+    c10::DeviceGuard guard(q.device());
+    MFA_CHECK_DEVICE(cu_seqlens_q);
+    MFA_CHECK_DEVICE(cu_seqlens_k);
+    TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_k.scalar_type() == at::kInt,
+                "cu_seqlens_q and cu_seqlens_k must be int32");
+    TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens must be contiguous");
+    TORCH_CHECK(cu_seqlens_q.numel() == cu_seqlens_k.numel() && cu_seqlens_q.numel() >= 1,
+                "cu_seqlens_q and cu_seqlens_k must have batch + 1 elements");
+    TORCH_CHECK(q.dim() == 3, "q must be (total_q, heads, head_dim)");
+    const int total_q = q.size(0), num_heads = q.size(1), head_dim = q.size(2);
+    const int batch = cu_seqlens_q.numel() - 1;
+    const int kv_num_heads = k.size(-2);
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    at::Tensor out = at::empty_like(q);
+    if (is_causal) window_size_right = 0;
+
+    mfa_forward_params p{};
+    set_tensor_strides(p, q, k, v, out, false);
+    p.batch = batch;
+    p.seqlen_q = max_seqlen_q;
+    p.seqlen_k = max_seqlen_k;
+    p.heads = num_heads;
+    p.kv_heads = kv_num_heads;
+    p.head_dim = head_dim;
+    p.cu_seqlens_q = cu_seqlens_q.data_ptr<int>();
+    p.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
+    mfa_forward_params_set_scale(&p);
+    set_windows(p, window_size_left, window_size_right, max_seqlen_k);
+
+    MFA_CHECK_SHAPE(q, total_q, num_heads, head_dim);
+    if (block_table_.has_value()) {
+        TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "paged k, v must be (num_blocks, page_block_size, heads_k, head_dim)");
+        const int num_blocks = k.size(0), page_block_size = k.size(1);
+        MFA_CHECK_SHAPE(k, num_blocks, page_block_size, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v, num_blocks, page_block_size, kv_num_heads, head_dim);
+        set_paged(p, block_table_.value(), k, v, batch);
+    } else {
+        // the reference requires total_k == total_q here (api.cpp:259-260); any total_k is accepted
+        TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "k, v must be (total_k, heads_k, head_dim)");
+        const int total_k = k.size(0);
+        MFA_CHECK_SHAPE(k, total_k, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v, total_k, kv_num_heads, head_dim);
+    }
+    check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
+    return out;
+}
+
+// reference: mfa::mha_fwd_kvcache, csrc/mfa/api.cpp:343-446
+at::Tensor mha_fwd_kvcache(const at::Tensor& q, const at::Tensor& k_cache, const at::Tensor& v_cache,
+                           const std::optional<at::Tensor>& seqlens_k_,
+                           const std::optional<at::Tensor>& block_table_, bool /*causal: ignored, api.cpp:349*/,
+                           int num_splits) {
+    check_dtypes(q, k_cache, v_cache);
+    c10::DeviceGuard guard(q.device());
+    TORCH_CHECK(q.dim() == 4 && k_cache.dim() == 4 && v_cache.dim() == 4, "q, k_cache, v_cache must be 4-D");
+    const int batch = q.size(0), seqlen_q = q.size(1), num_heads = q.size(2), head_dim = q.size(3);
+    TORCH_CHECK(seqlen_q == 1, "flash decoding expects seqlen_q == 1, got ", seqlen_q);
+    const bool paged_kv = block_table_.has_value();
+    const int kv_num_heads = k_cache.size(-2);
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    MFA_CHECK_SHAPE(q, batch, seqlen_q, num_heads, head_dim);
+
+    mfa_forward_params p{};
+    int seqlen_k;
+    if (paged_kv) {
+        const auto& block_table = block_table_.value();
+        TORCH_CHECK(block_table.dim() == 2, "block_table must be (batch, max_blocks_per_seq)");
+        const int page_block_size = k_cache.size(1), num_blocks = k_cache.size(0);
+        seqlen_k = block_table.size(1) * page_block_size;
+        MFA_CHECK_SHAPE(k_cache, num_blocks, page_block_size, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v_cache, num_blocks, page_block_size, kv_num_heads, head_dim);
+        set_paged(p, block_table, k_cache, v_cache, batch);
+    } else {
+        seqlen_k = k_cache.size(1);
+        MFA_CHECK_SHAPE(k_cache, batch, seqlen_k, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v_cache, batch, seqlen_k, kv_num_heads, head_dim);
+    }
+    at::Tensor out = at::empty_like(q);
+    set_tensor_strides(p, q, k_cache, v_cache, out, true);
+    p.batch = batch;
+    p.seqlen_q = seqlen_q;
+    p.seqlen_k = seqlen_k;
+    p.heads = num_heads;
+    p.kv_heads = kv_num_heads;
+    p.head_dim = head_dim;
+    mfa_forward_params_set_scale(&p);
+    set_windows(p, -1, -1, seqlen_k);
+
+    if (seqlens_k_.has_value()) {
+        const auto& seqlens_k = seqlens_k_.value();
+        MFA_CHECK_DEVICE(seqlens_k);
+        TORCH_CHECK(seqlens_k.scalar_type() == at::kInt, "seqlens_k must be int32");
+        TORCH_CHECK(seqlens_k.numel() == batch, "seqlens_k must have the same number of elements as batch size");
+        TORCH_CHECK(seqlens_k.is_contiguous(), "seqlens_k must be contiguous");
+        p.seqlens_k = seqlens_k.data_ptr<int>();
+    } // None = every sequence is seqlen_k long (the reference dereferences NULL here, decode.cuh:26)
+
+    auto opts = q.options().dtype(at::kFloat);
+    at::Tensor softmax_lse = at::empty({batch, num_heads}, opts);
+    p.softmax_lse_ptr = softmax_lse.data_ptr<float>();
+
+    // split choice + workspaces (reference: forward_params_set_split_kv, api.cpp:305-340); the kernel
+    // writes -inf LSE for empty splits itself, so no fill kernel is launched.
+    p.num_splits = mfa_num_splits_heuristic(num_splits, batch, kv_num_heads, seqlen_k, 0);
+    at::Tensor lse_accum, out_accum;
+    if (p.num_splits > 1) {
+        lse_accum = at::empty({p.num_splits, batch, num_heads}, opts);
+        out_accum = at::empty({p.num_splits, batch, num_heads, head_dim}, opts);
+        p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
+        p.oaccum_ptr = out_accum.data_ptr<float>();
+    }
+    check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
+    return out;
+}
+
+} // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+    m.doc() = "mini flash attention (MI355X / gfx950)";
+    // positional-only, same order as the reference's csrc/api.cpp:6-8
+    m.def("mini_flash_attention_forward", &flash_attention_forward, "Forward pass");
+    m.def("mini_flash_attention_varlen_forward", &flash_attention_varlen_forward,
+          "Forward pass with variable-length sequences");
+    m.def("mini_flash_attention_with_kvcache", &mha_fwd_kvcache, "Forward pass with kv-cache for decoding");
+}
