@@ -1,0 +1,187 @@
+"""bench.py — headline measurement of the attention-forward hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic input, already resident in HBM:
+  * headline (the JSON's metric/value): BASELINE config 2 — prefill, fp16, B=48 S=1024 H=24 D=128, causal,
+    through mini_flash_attention.flash_attn_func; value = whole-job TFLOP/s (FlashAttention convention: causal
+    FLOPs = 4*B*H*S^2*D / 2);
+  * "decode" object: BASELINE config 3 — bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128, num_splits auto, timed the
+    same way right after, reported as HBM GB/s of the algorithmic bytes (K+V once per KV head, + Q + O).
+Multi-GPU: the path is embarrassingly parallel over batch x heads and has no exchange step ("replicas only",
+DESIGN.md): every rank runs its own batch (weak scaling), the timed region is bracketed by barrier +
+synchronize, elapsed = MAX over ranks, value = all ranks' work / that time.
+`roofline` is for the dominant kernel of the headline step; `cpu_baseline` (rank 0, N=1 only) times the
+reference tests' own oracle — eager torch SDPA in fp32 on the host cores — on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "mini-flash-attention_amd"))
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense fp16/bf16, MI355X_MICROARCH.md chip table
+PEAK_HBM_GBPS = 8000.0     # HBM3E spec (≈6300 achievable copy)
+
+PREFILL = dict(B=48, S=1024, H=24, Hk=24, D=128, causal=True, dtype=torch.float16)
+DECODE = dict(B=24, Sk=8192, H=24, Hk=8, D=128, dtype=torch.bfloat16)
+
+
+def prefill_flops(c):
+    return 4.0 * c["B"] * c["H"] * c["S"] * c["S"] * c["D"] * (0.5 if c["causal"] else 1.0)
+
+
+def prefill_bytes(c):
+    return 2.0 * (2 * c["B"] * c["S"] * c["H"] * c["D"] + 2 * c["B"] * c["S"] * c["Hk"] * c["D"])
+
+
+def decode_bytes(c):
+    return 2.0 * (2 * c["B"] * c["Sk"] * c["Hk"] * c["D"] + 2 * c["B"] * c["H"] * c["D"])
+
+
+def timed_region(fn, steps, warmup, dist):
+    """W untimed steps, then exactly K steps between barrier+synchronize pairs.  Returns (wall seconds MAX over
+    ranks, mean device ms per step from HIP events on the launch stream)."""
+    for _ in range(warmup):
+        fn()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if dist:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    start.record()
+    for _ in range(steps):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    if dist:
+        torch.distributed.barrier()
+    wall = time.perf_counter() - t0
+    ev_ms = start.elapsed_time(end) / steps
+    if dist:
+        t = torch.tensor([wall, ev_ms], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        wall, ev_ms = t[0].item(), t[1].item()
+    return wall, ev_ms
+
+
+def cpu_baseline(c, budget_s=20.0):
+    """Eager torch SDPA, fp32, on the host cores (what reference tests/test_mha.py:75-81 uses as its oracle),
+    on a batch slice of the headline workload sized to ~budget_s of CPU work."""
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(0)
+    b = 1
+    q, k, v = (torch.randn(b, c["H"], c["S"], c["D"], generator=g) for _ in range(3))
+    t = time.perf_counter()
+    F.scaled_dot_product_attention(q, k, v, is_causal=c["causal"])
+    per_b = time.perf_counter() - t
+    b = int(max(1, min(c["B"], budget_s / max(per_b, 1e-4) / 4)))
+    q, k, v = (torch.randn(b, c["H"], c["S"], c["D"], generator=g) for _ in range(3))
+    F.scaled_dot_product_attention(q, k, v, is_causal=c["causal"])
+    times = []
+    for _ in range(3):
+        t = time.perf_counter()
+        F.scaled_dot_product_attention(q, k, v, is_causal=c["causal"])
+        times.append(time.perf_counter() - t)
+    med = sorted(times)[1]
+    flops = prefill_flops(dict(c, B=b))
+    return {
+        "value": round(flops / med / 1e12, 4), "unit": "TFLOP/s", "cores": threads, "kind": "port",
+        "sample": f"torch SDPA eager fp32 on host CPU, B={b} slice of the headline workload (H={c['H']} S={c['S']} "
+                  f"D={c['D']} causal), median of 3 runs, {med * 1e3:.1f} ms/run, os.cpu_count()={os.cpu_count()}",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if dist:
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world if dist else 1
+
+    import mini_flash_attention as mfa  # fails loudly when the HIP extension is missing
+
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(rank)
+    c = PREFILL
+    q = torch.randn(c["B"], c["S"], c["H"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"])
+    k = torch.randn(c["B"], c["S"], c["Hk"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"])
+    v = torch.randn(c["B"], c["S"], c["Hk"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"])
+    wall, ev_ms = timed_region(lambda: mfa.flash_attn_func(q, k, v, causal=c["causal"]), args.steps, args.warmup, dist)
+    ms_per_step = wall / args.steps * 1e3
+    tflops = prefill_flops(c) * n_gpus * args.steps / wall / 1e12
+    kern_s = ev_ms * 1e-3
+    kern_tflops = prefill_flops(c) / kern_s / 1e12
+    kern_gbps = prefill_bytes(c) / kern_s / 1e9
+    # binding roof = max(FLOPs / P_mfma, bytes / BW_hbm)   (config 2 sits on the ridge, HBM side)
+    t_mfma = prefill_flops(c) / (PEAK_MFMA_TFLOPS * 1e12)
+    t_hbm = prefill_bytes(c) / (PEAK_HBM_GBPS * 1e9)
+    if t_hbm >= t_mfma:
+        roof = {"bound": "hbm", "achieved": round(kern_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(kern_gbps / PEAK_HBM_GBPS, 4)}
+    else:
+        roof = {"bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4)}
+    roof.update({"traffic": None, "kernel": "prefill_fwd_kernel<Half,128>", "kernel_ms": round(ev_ms, 4),
+                 "mfma_tflops": round(kern_tflops, 1), "mfma_frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4),
+                 "hbm_gbps": round(kern_gbps, 1), "hbm_frac": round(kern_gbps / PEAK_HBM_GBPS, 4),
+                 "algorithmic_flops": prefill_flops(c), "algorithmic_bytes": prefill_bytes(c)})
+    del q, k, v
+
+    d = DECODE
+    qd = torch.randn(d["B"], 1, d["H"], d["D"], device=dev, dtype=torch.float32).to(d["dtype"])
+    kc = torch.randn(d["B"], d["Sk"], d["Hk"], d["D"], device=dev, dtype=torch.float32).to(d["dtype"])
+    vc = torch.randn(d["B"], d["Sk"], d["Hk"], d["D"], device=dev, dtype=torch.float32).to(d["dtype"])
+    lens = torch.full((d["B"],), d["Sk"], dtype=torch.int32, device=dev)
+    dwall, dev_ms = timed_region(lambda: mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=0),
+                                 args.steps, args.warmup, dist)
+    dec_gbps = decode_bytes(d) * n_gpus * args.steps / dwall / 1e9
+    dec_kern_gbps = decode_bytes(d) / (dev_ms * 1e-3) / 1e9
+    decode = {
+        "metric": "decode HBM GB/s", "value": round(dec_gbps, 1), "unit": "GB/s", "us_per_step": round(dwall / args.steps * 1e6, 2),
+        "dtype": "bf16",
+        "config": {"workload": "flash-decoding bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128 num_splits=auto (BASELINE config 3)"},
+        "roofline": {"bound": "hbm", "achieved": round(dec_kern_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": round(dec_kern_gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "kernel": "decode_split_kv_kernel + decode_combine_kernel", "kernel_us": round(dev_ms * 1e3, 2),
+                     "algorithmic_bytes": decode_bytes(d)},
+    }
+
+    if rank == 0:
+        out = {
+            "metric": "prefill attention TFLOPS (fp16, head_dim=128, causal) + decode HBM GB/s, 1xMI355X",
+            "value": round(tflops, 2), "unit": "TFLOP/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "prefill fp16 B=48 S=1024 H=24 D=128 causal per GPU (BASELINE config 2, benchmark/prefill.py shape)",
+                       "parallelism": f"replicas x{n_gpus} (no collective on the data path)"},
+            "roofline": roof, "decode": decode,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c)
+        print(json.dumps(out), flush=True)
+    if dist:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,6 +106,7 @@ typedef struct mfa_forward_params {
 int mfa_abi_version(void);
 const char* mfa_version(void);
 const char* mfa_last_error(void);
+size_t mfa_forward_params_sizeof(void); /* sizeof(mfa_forward_params) the library was built with */
 
 /* softmax_scale = 1/sqrt(head_dim), softmax_scale_log2 = softmax_scale*log2(e); kv_group_size. */
 void mfa_forward_params_set_scale(mfa_forward_params* p);

@@ -67,6 +67,8 @@ const char* mfa_version(void) { return "mini-flash-attention gfx950 0.1.0"; }
 
 const char* mfa_last_error(void) { return g_err; }
 
+size_t mfa_forward_params_sizeof(void) { return sizeof(mfa_forward_params); }
+
 void mfa_forward_params_set_scale(mfa_forward_params* p) {
     if (!p || p->head_dim <= 0) return;
     // reference: csrc/mfa/api.cpp:84, 99-100
