@@ -46,6 +46,15 @@ def decode_bytes(c):
     return 2.0 * (2 * c["B"] * c["Sk"] * c["Hk"] * c["D"] + 2 * c["B"] * c["H"] * c["D"])
 
 
+def measured_traffic(key):
+    """Per-launch HBM bytes from the last committed rocprofv3 PMC passes (profiles/traffic.json), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
 def timed_region(fn, steps, warmup, dist):
     """W untimed steps, then exactly K steps between barrier+synchronize pairs.  Returns (wall seconds MAX over
     ranks, mean device ms per step from HIP events on the launch stream)."""
@@ -141,7 +150,7 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4)}
-    roof.update({"traffic": None, "kernel": "prefill_fwd_kernel<Half,128>", "kernel_ms": round(ev_ms, 4),
+    roof.update({"traffic": measured_traffic("prefill"), "kernel": "prefill_fwd_kernel<Half,128>", "kernel_ms": round(ev_ms, 4),
                  "mfma_tflops": round(kern_tflops, 1), "mfma_frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4),
                  "hbm_gbps": round(kern_gbps, 1), "hbm_frac": round(kern_gbps / PEAK_HBM_GBPS, 4),
                  "algorithmic_flops": prefill_flops(c), "algorithmic_bytes": prefill_bytes(c)})
@@ -161,7 +170,7 @@ def main():
         "dtype": "bf16",
         "config": {"workload": "flash-decoding bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128 num_splits=auto (BASELINE config 3)"},
         "roofline": {"bound": "hbm", "achieved": round(dec_kern_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": round(dec_kern_gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "frac": round(dec_kern_gbps / PEAK_HBM_GBPS, 4), "traffic": measured_traffic("decode"),
                      "kernel": "decode_split_kv_kernel + decode_combine_kernel", "kernel_us": round(dev_ms * 1e3, 2),
                      "algorithmic_bytes": decode_bytes(d)},
     }
