@@ -71,8 +71,8 @@ __device__ __forceinline__ int v_swz(int row) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs a) {
+template <typename T, int D, int NW, bool PAGED>
+__global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
     using E = Elem<T>;
     using frag8 = typename E::frag8;
     constexpr int RB = Pitch<D>::RB;
@@ -151,19 +151,19 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
     }
 
     // ---- staging: thread t moves chunk (t + i*NT) of the tile: row = idx / CH, ch = idx % CH ------
+    // Branch-free: rows past the key length are clamped to the last valid row for the load (their scores are
+    // masked, and the V image is zeroed for them on the one ragged tile, so 0 * garbage never reaches O).
     u32x4 kst[CPT], vst[CPT];
+    const int last_key = max(sk - 1, 0);
     auto stage_load = [&](int j) {
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int idx = tid + i * NT;
             const int row = idx / CH, ch = idx - row * CH;
-            const int key = j * kBN + row;
-            u32x4 z = {0, 0, 0, 0};
-            kst[i] = z;
-            vst[i] = z;
-            if ((TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) && key < sk) {
+            const int key = min(j * kBN + row, last_key);
+            if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
                 int64_t ko, vo;
-                if (table) {
+                if constexpr (PAGED) {
                     const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
                     const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
                     const int64_t pid = table[min(pg, a.max_blocks - 1)];
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
             }
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int j, int buf) {
+        const bool ragged = (j + 1) * kBN > sk; // wave-uniform: only the last tile of a sequence
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int idx = tid + i * NT;
@@ -186,8 +187,10 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
                 const int row = idx / CH, ch = idx - row * CH;
                 const int kch = ch ^ k_swz<RB>(row);
                 const int vch = (((ch >> 2) ^ v_swz<RB>(row)) << 2) | (ch & 3);
+                u32x4 vv = vst[i];
+                if (ragged && j * kBN + row >= sk) vv = u32x4{0, 0, 0, 0};
                 *(u32x4*)(sK + buf * TILE_BYTES + row * RB + 16 * kch) = kst[i];
-                *(u32x4*)(sV + buf * TILE_BYTES + row * RB + 16 * vch) = vst[i];
+                *(u32x4*)(sV + buf * TILE_BYTES + row * RB + 16 * vch) = vv;
             }
         }
     };
@@ -216,10 +219,12 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
     const float c = a.scale_log2;
     const int wrow0 = m0 + 32 * wave; // first query row of this wave
 
-    if (nt > 0) {
-        stage_load(0);
-        stage_write(0);
-    }
+    if (nt > 0 && sk > 0) stage_load(0);
+    // Everything loaded so far (Q fragments, tile 0) is waited for HERE: with the Q loads still on the
+    // scoreboard at the loop header, hipcc re-waits for them inside the loop (vmcnt(7..0) before the QK^T
+    // MFMAs), which from the second iteration on drains the just-issued staging loads of the next tile.
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+    if (nt > 0 && sk > 0) stage_write(0, 0);
     __syncthreads();
 
     for (int j = 0; j < nt; ++j) {
@@ -234,14 +239,24 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
             const char* vt = sV + cur * TILE_BYTES;
             f32x16 s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
+            // K fragments: row 32*kb + r, chunk 2*ks + h; read PF k-steps ahead of the MFMAs that use them
+            constexpr int PF = KS < 2 ? KS : 2;
+            frag8 kf[KS][2];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+            for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const frag8 kf = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * ks) ^ k_xh));
-                    s[kb] = E::mfma32(kf, qf[ks], s[kb]);
+                for (int kb = 0; kb < 2; ++kb)
+                    kf[ks][kb] = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * ks) ^ k_xh));
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + PF < KS) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+                        kf[ks + PF][kb] = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * (ks + PF)) ^ k_xh));
                 }
+                s[0] = E::mfma32(kf[ks][0], qf[ks], s[0]);
+                s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
             }
             // mask: key > query row (top-left causal) or key >= sk
             const bool need_mask = (a.is_causal && j * kBN + kBN - 1 > wrow0) || (j + 1) * kBN > sk;
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
                 }
             }
         }
-        if (more) stage_write(cur ^ 1);
+        if (more) stage_write(j + 1, cur ^ 1);
         __syncthreads();
     }
 
@@ -344,8 +359,8 @@ __global__ __launch_bounds__(64 * NW) void prefill_fwd_kernel(const PrefillArgs 
     }
 }
 
-template <typename T, int D, int NW>
-static int launch_prefill_t(PrefillArgs& a, hipStream_t stream) {
+template <typename T, int D, int NW, bool PAGED>
+static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     constexpr int RB = Pitch<D>::RB;
     constexpr size_t smem = 4 * kBN * RB;
@@ -354,18 +369,17 @@ static int launch_prefill_t(PrefillArgs& a, hipStream_t stream) {
     if (total <= 0) return 0;
     if (total > 0x7fffffffLL) return -1;
     a.total_blocks = (int)total;
-    auto kern = prefill_fwd_kernel<T, D, NW>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (smem > 64 * 1024) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) !=
-                hipSuccess)
-                return -3;
-        }
-        attr_set = true;
-    }
+    auto kern = prefill_fwd_kernel<T, D, NW, PAGED>;
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return -3;
     hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * NW), smem, stream, a);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T, int D, int NW>
+static int launch_prefill_t(PrefillArgs& a, hipStream_t stream) {
+    return a.block_table ? launch_prefill_p<T, D, NW, true>(a, stream) : launch_prefill_p<T, D, NW, false>(a, stream);
 }
 
 template <typename T>
