@@ -18,6 +18,8 @@
 //   * O leaves through LDS as whole rows (16-byte coalesced stores);
 //   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
 //     run on one XCD (shared L2), heaviest causal blocks first.
+#include <type_traits>
+
 #include "mfa_device.h"
 #include "mfa_launch.h"
 
@@ -153,60 +155,103 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // ---- staging: thread t moves chunk (t + i*NT) of the tile: row = idx / CH, ch = idx % CH ------
     // Branch-free: rows past the key length are clamped to the last valid row for the load (their scores are
     // masked, and the V image is zeroed for them on the one ragged tile, so 0 * garbage never reaches O).
+    // REGULAR tiles (NT % CH == 0, not paged): chunk i of a thread is row0 + i*RPP at a fixed 16-byte column, so
+    // the global offset is one 32-bit add per chunk on a wave-uniform base and every LDS address is a per-thread
+    // base plus an immediate.
+    constexpr bool REGULAR = !PAGED && (NT % CH == 0) && (TILE_CHUNKS % NT == 0);
+    constexpr int RPP = REGULAR ? NT / CH : 1; // rows per pass
     u32x4 kst[CPT], vst[CPT];
     const int last_key = max(sk - 1, 0);
+    const int row0 = tid / CH, ch0 = tid - row0 * CH;
+    const uint32_t k_sb = (uint32_t)(2 * a.k_row_stride), v_sb = (uint32_t)(2 * a.v_row_stride); // row pitch, bytes
+    const uint32_t k_go = row0 * k_sb + 16 * ch0, v_go = row0 * v_sb + 16 * ch0;
+    const uint32_t k_gmax = last_key * k_sb + 16 * ch0, v_gmax = last_key * v_sb + 16 * ch0;
     auto stage_load = [&](int j) {
+        if constexpr (REGULAR) {
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int idx = tid + i * NT;
-            const int row = idx / CH, ch = idx - row * CH;
-            const int key = min(j * kBN + row, last_key);
-            if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
-                int64_t ko, vo;
-                if constexpr (PAGED) {
-                    const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
-                    const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
-                    const int64_t pid = table[min(pg, a.max_blocks - 1)];
-                    ko = pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
-                    vo = pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
-                } else {
-                    ko = (int64_t)key * a.k_row_stride;
-                    vo = (int64_t)key * a.v_row_stride;
+            for (int i = 0; i < CPT; ++i) {
+                const uint32_t rows = (uint32_t)(j * kBN + i * RPP); // wave-uniform
+                kst[i] = *(const u32x4*)(kbase + min(k_go + rows * k_sb, k_gmax));
+                vst[i] = *(const u32x4*)(vbase + min(v_go + rows * v_sb, v_gmax));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int idx = tid + i * NT;
+                const int row = idx / CH, ch = idx - row * CH;
+                const int key = min(j * kBN + row, last_key);
+                if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
+                    int64_t ko, vo;
+                    if constexpr (PAGED) {
+                        const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+                        const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
+                        const int64_t pid = table[min(pg, a.max_blocks - 1)];
+                        ko = pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
+                        vo = pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
+                    } else {
+                        ko = (int64_t)key * a.k_row_stride;
+                        vo = (int64_t)key * a.v_row_stride;
+                    }
+                    kst[i] = *(const u32x4*)(kbase + 2 * ko + 16 * ch);
+                    vst[i] = *(const u32x4*)(vbase + 2 * vo + 16 * ch);
                 }
-                kst[i] = *(const u32x4*)(kbase + 2 * ko + 16 * ch);
-                vst[i] = *(const u32x4*)(vbase + 2 * vo + 16 * ch);
             }
         }
     };
-    auto stage_write = [&](int j, int buf) {
+    // LDS write addresses of chunk 0; for REGULAR tiles chunk i is at + i*RPP*RB when the swizzles do not change
+    // with the row step (RPP % 16 == 0), which the generic expression below also covers.
+    auto lds_k_off = [&](int row, int ch) { return row * RB + 16 * (ch ^ k_swz<RB>(row)); };
+    auto lds_v_off = [&](int row, int ch) { return row * RB + 16 * ((((ch >> 2) ^ v_swz<RB>(row)) << 2) | (ch & 3)); };
+    char* const kw0 = sK + lds_k_off(row0, ch0);
+    char* const vw0 = sV + lds_v_off(row0, ch0);
+    auto stage_write = [&](int j, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
         const bool ragged = (j + 1) * kBN > sk; // wave-uniform: only the last tile of a sequence
 #pragma unroll
         for (int i = 0; i < CPT; ++i) {
             const int idx = tid + i * NT;
             if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
-                const int row = idx / CH, ch = idx - row * CH;
-                const int kch = ch ^ k_swz<RB>(row);
-                const int vch = (((ch >> 2) ^ v_swz<RB>(row)) << 2) | (ch & 3);
-                u32x4 vv = vst[i];
-                if (ragged && j * kBN + row >= sk) vv = u32x4{0, 0, 0, 0};
-                *(u32x4*)(sK + buf * TILE_BYTES + row * RB + 16 * kch) = kst[i];
-                *(u32x4*)(sV + buf * TILE_BYTES + row * RB + 16 * vch) = vv;
+                int row;
+                char *kw, *vw;
+                if constexpr (REGULAR && RPP % 16 == 0) {
+                    row = row0 + i * RPP;
+                    kw = kw0 + i * RPP * RB;
+                    vw = vw0 + i * RPP * RB;
+                } else {
+                    row = idx / CH;
+                    const int ch = idx - row * CH;
+                    kw = sK + lds_k_off(row, ch);
+                    vw = sV + lds_v_off(row, ch);
+                }
+                if (ragged) { // uniform branch: zero the V rows past the key length
+                    if (j * kBN + row >= sk) vst[i] = u32x4{0, 0, 0, 0};
+                }
+                *(u32x4*)(kw + BUF * TILE_BYTES) = kst[i];
+                *(u32x4*)(vw + BUF * TILE_BYTES) = vst[i];
             }
         }
     };
 
-    // ---- per-lane LDS read addresses -----------------------------------------------------------
-    // K fragment (A operand): row 32*kb + r, chunk 2*ks + h  ->  16*((2*ks) ^ (swz ^ h))
+    // ---- per-lane LDS read addresses (bases; tile buffer, key block and k-step are immediates) ------
+    // K fragment (A operand): row 32*kb + r, chunk (2*ks + h) ^ swz(r)
     const int k_xh = k_swz<RB>(r) ^ h;
-    const int k_row_off = r * RB;
+    // (absolute LDS pointers, formed once: `smem + offset` inside the loop costs a v_add per access because the
+    // dynamic-LDS base is a link-time symbol the compiler cannot fold into the DS immediate)
+    const char* k_rd[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) k_rd[ks] = smem + r * RB + 16 * ((2 * ks) ^ k_xh);
     // V^T fragment via transposed read: 16-lane group g16 = lane>>4 : h = g16>>1, column half = g16&1;
     // lane 4q+p of the group addresses key 16*s + 4h + q (+8 for the second read), columns 4p..4p+3 of
-    // the 16-column half, i.e. byte (32*db + 16*(g16&1) + 4p)*2 of the row.
+    // the 16-column half, i.e. byte (32*db + 16*(g16&1) + 4p)*2 of the row.  The 64-byte unit of column
+    // block db is (db ^ swz(key)), i.e. the low two bits of db are XORed: one base per (db & 3).
     const int tq = (lane >> 2) & 3, tp = lane & 3, tcol = (lane >> 4) & 1;
-    const int v_key0 = 4 * h + tq;                        // + 16*s (+8)
+    const int v_key0 = 4 * h + tq;                                 // + 16*s (+8)
     const int v_in64 = (2 * tcol + (tp >> 1)) * 16 + (tp & 1) * 8; // byte inside the 64-byte unit
-    // v_swz(row) depends on key&3 (= tq, RB>=256) or (key>>1)&1 (RB==128); +8/+16*s leave both unchanged
-    const int v_x = v_swz<RB>(v_key0);
+    const int v_x = v_swz<RB>(v_key0); // depends on key&3 / (key>>1)&1 only: unchanged by +8, +16*s
+    constexpr int NVB = DB < 4 ? DB : 4;
+    const char* v_rd[NVB];
+#pragma unroll
+    for (int d = 0; d < NVB; ++d) v_rd[d] = smem + 2 * TILE_BYTES + v_key0 * RB + v_in64 + ((d ^ v_x) * 64);
 
     float m_run = -INFINITY; // running max of RAW scores (prefill.cuh:454-462)
     float l_run = 0.f;       // this lane's partial row sum (its 32 keys of every tile)
@@ -224,36 +269,35 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // scoreboard at the loop header, hipcc re-waits for them inside the loop (vmcnt(7..0) before the QK^T
     // MFMAs), which from the second iteration on drains the just-issued staging loads of the next tile.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    if (nt > 0 && sk > 0) stage_write(0, 0);
+    if (nt > 0 && sk > 0) stage_write(0, std::integral_constant<int, 0>{});
     __syncthreads();
 
-    for (int j = 0; j < nt; ++j) {
-        const int cur = j & 1;
+    // one key tile out of LDS buffer BUF (compile-time, so every LDS offset is an immediate)
+    auto tile = [&](int j, auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
         const bool more = j + 1 < nt;
         if (more) stage_load(j + 1);
 
         // a wave whose rows all precede this tile's first key has nothing to do under the causal mask
         const bool active = !a.is_causal || j * kBN <= wrow0 + 31;
         if (active) {
-            const char* kt = sK + cur * TILE_BYTES;
-            const char* vt = sV + cur * TILE_BYTES;
+            constexpr int kt = BUF * TILE_BYTES; // byte offset of this tile's K (and, past sK, V) buffer
+            constexpr int vt = BUF * TILE_BYTES;
             f32x16 s[2];
 #pragma unroll
             for (int i = 0; i < 16; ++i) s[0][i] = s[1][i] = 0.f;
-            // K fragments: row 32*kb + r, chunk 2*ks + h; read PF k-steps ahead of the MFMAs that use them
+            // K fragments are read PF k-steps ahead of the MFMAs that use them
             constexpr int PF = KS < 2 ? KS : 2;
             frag8 kf[KS][2];
 #pragma unroll
             for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    kf[ks][kb] = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * ks) ^ k_xh));
+                for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *(const frag8*)(k_rd[ks] + kt + kb * 32 * RB);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 if (ks + PF < KS) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-                        kf[ks + PF][kb] = *(const frag8*)(kt + kb * 32 * RB + k_row_off + 16 * ((2 * (ks + PF)) ^ k_xh));
+                    for (int kb = 0; kb < 2; ++kb) kf[ks + PF][kb] = *(const frag8*)(k_rd[ks + PF] + kt + kb * 32 * RB);
                 }
                 s[0] = E::mfma32(kf[ks][0], qf[ks], s[0]);
                 s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
@@ -261,14 +305,13 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             // mask: key > query row (top-left causal) or key >= sk
             const bool need_mask = (a.is_causal && j * kBN + kBN - 1 > wrow0) || (j + 1) * kBN > sk;
             if (need_mask) {
-                const int lim = a.is_causal ? min(qrow, sk - 1) : sk - 1; // keys <= lim stay
+                // keys <= lim stay; register i of block kb is key j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
+                const int lim = (a.is_causal ? min(qrow, sk - 1) : sk - 1) - j * kBN - 4 * h;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int key = j * kBN + 32 * kb + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (key > lim) s[kb][i] = -INFINITY;
-                    }
+                    for (int i = 0; i < 16; ++i)
+                        if (32 * kb + (i & 3) + 8 * (i >> 2) > lim) s[kb][i] = -INFINITY;
             }
             // ---- online softmax, all in this lane's registers ---------------------------------------
             float mt = s[0][0];
@@ -279,9 +322,17 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             mt = fmaxf(mt, swap32(mt));
             const float m_new = fmaxf(m_run, mt);
             const float ms = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = fast_exp2((m_run - ms) * c);
             const float mc = ms * c;
-            m_run = m_new;
+            // rescale O and l only when some row of this wave raised its max (alpha == 1 exactly otherwise)
+            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
+                const float alpha = fast_exp2((m_run - ms) * c);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+                m_run = m_new;
+            }
             float psum = 0.f;
             uint32_t pk[2][8];
 #pragma unroll
@@ -293,11 +344,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     psum += p0 + p1;
                     pk[kb][i] = E::pack(p0, p1);
                 }
-            l_run = l_run * alpha + psum;
-#pragma unroll
-            for (int d = 0; d < DB; ++d)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
+            l_run += psum;
 
             // ---- O^T += V^T . P^T : 4 k-steps of 16 keys x DB column blocks ---------------------------
 #pragma unroll
@@ -305,20 +352,24 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 const int kb = s16 >> 1, sh = s16 & 1;
                 u32x4 pw = {pk[kb][4 * sh], pk[kb][4 * sh + 1], pk[kb][4 * sh + 2], pk[kb][4 * sh + 3]};
                 const frag8 pf = __builtin_bit_cast(frag8, pw);
-                const char* vrow = vt + (16 * s16 + v_key0) * RB + v_in64;
 #pragma unroll
                 for (int d = 0; d < DB; ++d) {
-                    const int unit = (d ^ v_x) * 64;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + unit));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(vrow + 8 * RB + unit));
+                    const char* va = v_rd[d & 3] + vt + (d >> 2) * 256 + s16 * 16 * RB;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * RB));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
                 }
             }
         }
-        if (more) stage_write(j + 1, cur ^ 1);
+        if (more) stage_write(j + 1, std::integral_constant<int, BUF ^ 1>{});
         __syncthreads();
+    };
+
+    for (int j = 0; j < nt; j += 2) {
+        tile(j, std::integral_constant<int, 0>{});
+        if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
     }
 
     // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
