@@ -25,6 +25,8 @@ HIP_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-math-errno",
     "-Wno-unused-result", "-mllvm", "-amdgpu-early-inline-all=true",
 ]
+if os.environ.get("MFA_ABLATION"):  # developer builds only: timing-only kernel variants selected by $MFA_ABLATE
+    HIP_FLAGS.append("-DMFA_ABLATION")
 
 
 def _run(cmd):

@@ -18,6 +18,7 @@
 //   * O leaves through LDS as whole rows (16-byte coalesced stores);
 //   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
 //     run on one XCD (shared L2), heaviest causal blocks first.
+#include <cstdlib>
 #include <type_traits>
 
 #include "mfa_device.h"
@@ -42,7 +43,7 @@ struct PrefillArgs {
     int32_t seqlen_q, seqlen_k; // dense lengths, or max lengths when varlen
     int32_t page_size, page_shift, max_blocks;
     int32_t num_m_blocks;
-    int32_t total_blocks;
+    int32_t group_pairs; // (batch, head) pairs per scheduling group
     int32_t is_causal;
     float scale_log2;
 };
@@ -73,7 +74,7 @@ __device__ __forceinline__ int v_swz(int row) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <typename T, int D, int NW, bool PAGED>
+template <typename T, int D, int NW, bool PAGED, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
     using E = Elem<T>;
     using frag8 = typename E::frag8;
@@ -97,20 +98,30 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const int r = lane & 31;
     const int h = lane >> 5;
 
-    // ---- workgroup -> (batch, head, query block): XCD-aware, bijective ---------------------------
-    int vid;
-    {
-        const int bid = blockIdx.x, n = a.total_blocks;
-        const int q8 = n >> 3, r8 = n & 7, x = bid & 7;
-        vid = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (bid >> 3);
-    }
+    // ---- workgroup -> (batch, head, query block) -------------------------------------------------
+    // XCD-aware: blocks bid, bid+8, ... share an XCD (round-robin dispatch), so XCD x = bid & 7 owns a contiguous
+    // range of (batch, head) pairs and their K/V stay in that XCD's L2.  Inside an XCD the pairs are taken in
+    // groups of `gp`; a group is walked query-block-major (heaviest causal block of each pair first), so that
+    // consecutive workgroups carry EQUAL work: the dispatcher deals consecutive workgroups round-robin over the
+    // XCD's shader engines, and a heavy-to-light sequence inside one pair lands the heavy blocks on the same
+    // engines every time (measured: 70 % wave-slot occupancy with pair-major order vs 94 % non-causal).
     const int nmb = a.num_m_blocks;
-    int mblk = vid % nmb;
-    const int bh = vid / nmb;
+    const int npairs = a.batch * a.heads;
+    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int p8 = npairs >> 3, r8 = npairs & 7;
+    const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
+    const int pair_count = p8 + (x < r8 ? 1 : 0);
+    const int gp = a.group_pairs;
+    const int g = k / (gp * nmb), t = k - g * (gp * nmb);
+    const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
+    if (gsize <= 0) return;
+    const int rank = t / gsize, pi = t - rank * gsize;
+    if (rank >= nmb) return; // padding of a short group
+    const int bh = pair_begin + g * gp + pi;
+    const int mblk = nmb - 1 - rank; // heaviest causal blocks first
     const int hq = bh % a.heads;
     const int b = bh / a.heads;
     const int hk = hq / a.group;
-    mblk = nmb - 1 - mblk; // heaviest causal blocks first
 
     int sq, sk;
     int64_t q_off, o_off, k_off, v_off;
@@ -152,83 +163,58 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const frag8*)(qp + 32 * ks);
     }
 
-    // ---- staging: thread t moves chunk (t + i*NT) of the tile: row = idx / CH, ch = idx % CH ------
-    // Branch-free: rows past the key length are clamped to the last valid row for the load (their scores are
-    // masked, and the V image is zeroed for them on the one ragged tile, so 0 * garbage never reaches O).
-    // REGULAR tiles (NT % CH == 0, not paged): chunk i of a thread is row0 + i*RPP at a fixed 16-byte column, so
-    // the global offset is one 32-bit add per chunk on a wave-uniform base and every LDS address is a per-thread
-    // base plus an immediate.
-    constexpr bool REGULAR = !PAGED && (NT % CH == 0) && (TILE_CHUNKS % NT == 0);
-    constexpr int RPP = REGULAR ? NT / CH : 1; // rows per pass
-    u32x4 kst[CPT], vst[CPT];
+    // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4), no VGPR round trip --------------
+    // One wave-instruction writes 1 KiB of LDS contiguously in lane order = RPI = 1024/RB whole tile rows; lane l
+    // sits at row (l / LPR), 16-byte position p = l % LPR of that piece.  The LDS image is swizzled (K: chunk ^
+    // swz(row) for the ds_read_b128 fragments; V: 64-byte unit ^ swz(row) for the transposed reads), so the lane at
+    // position p FETCHES the global chunk that belongs there (swizzle on the source address; the destination
+    // cannot scatter).  Rows past the key length are clamped to the last valid row: their scores are masked to
+    // -inf, so P is exactly 0 there and the duplicated (finite) V rows contribute nothing.
+    constexpr int LPR_ = RB / 16;            // lanes (16-byte positions) per LDS row
+    constexpr int RPI = 64 / LPR_;           // rows per wave-instruction
+    constexpr int NI = kBN / (RPI * NW) > 0 ? kBN / (RPI * NW) : 1; // instructions per wave per tile (K, and V)
+    static_assert(kBN % (RPI * NW) == 0 || kBN / (RPI * NW) == 0, "tile rows must split evenly over the waves");
     const int last_key = max(sk - 1, 0);
-    const int row0 = tid / CH, ch0 = tid - row0 * CH;
+    const int srow = wave * RPI + lane / LPR_; // row of this lane inside instruction 0 (+ i*RPI*NW for instruction i)
+    const int spos = lane % LPR_;
+    // source chunk for this lane's position; positions whose chunk lies in the row padding fetch chunk 0 (never read).
+    // v_swz is invariant under row += RPI*NW for every RB; k_swz is too unless RPI*NW = 8 (RB = 512), where
+    // instruction i flips bit 3 of the chunk for odd i.
+    constexpr bool KSWZ_FIXED = (RPI * NW) % 16 == 0;
+    auto k_src_chunk = [&](int row) { const int ch = spos ^ k_swz<RB>(row); return ch < CH ? ch : 0; };
+    const int s_kch = k_src_chunk(srow);
+    const int s_vch0 = (((spos >> 2) ^ v_swz<RB>(srow)) << 2) | (spos & 3);
+    const int s_vch = s_vch0 < CH ? s_vch0 : 0;
     const uint32_t k_sb = (uint32_t)(2 * a.k_row_stride), v_sb = (uint32_t)(2 * a.v_row_stride); // row pitch, bytes
-    const uint32_t k_go = row0 * k_sb + 16 * ch0, v_go = row0 * v_sb + 16 * ch0;
-    const uint32_t k_gmax = last_key * k_sb + 16 * ch0, v_gmax = last_key * v_sb + 16 * ch0;
-    auto stage_load = [&](int j) {
-        if constexpr (REGULAR) {
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const uint32_t rows = (uint32_t)(j * kBN + i * RPP); // wave-uniform
-                kst[i] = *(const u32x4*)(kbase + min(k_go + rows * k_sb, k_gmax));
-                vst[i] = *(const u32x4*)(vbase + min(v_go + rows * v_sb, v_gmax));
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < CPT; ++i) {
-                const int idx = tid + i * NT;
-                const int row = idx / CH, ch = idx - row * CH;
-                const int key = min(j * kBN + row, last_key);
-                if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
-                    int64_t ko, vo;
-                    if constexpr (PAGED) {
-                        const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
-                        const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
-                        const int64_t pid = table[min(pg, a.max_blocks - 1)];
-                        ko = pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
-                        vo = pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
-                    } else {
-                        ko = (int64_t)key * a.k_row_stride;
-                        vo = (int64_t)key * a.v_row_stride;
-                    }
-                    kst[i] = *(const u32x4*)(kbase + 2 * ko + 16 * ch);
-                    vst[i] = *(const u32x4*)(vbase + 2 * vo + 16 * ch);
-                }
-            }
-        }
-    };
-    // LDS write addresses of chunk 0; for REGULAR tiles chunk i is at + i*RPP*RB when the swizzles do not change
-    // with the row step (RPP % 16 == 0), which the generic expression below also covers.
-    auto lds_k_off = [&](int row, int ch) { return row * RB + 16 * (ch ^ k_swz<RB>(row)); };
-    auto lds_v_off = [&](int row, int ch) { return row * RB + 16 * ((((ch >> 2) ^ v_swz<RB>(row)) << 2) | (ch & 3)); };
-    char* const kw0 = sK + lds_k_off(row0, ch0);
-    char* const vw0 = sV + lds_v_off(row0, ch0);
-    auto stage_write = [&](int j, auto bufc) {
+    const uint32_t k_go = srow * k_sb + 16 * s_kch, v_go = srow * v_sb + 16 * s_vch;
+    const uint32_t k_gmax = last_key * k_sb + 16 * s_kch, v_gmax = last_key * v_sb + 16 * s_vch;
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto stage_dma = [&](int j, auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        const bool ragged = (j + 1) * kBN > sk; // wave-uniform: only the last tile of a sequence
+        if (NI * RPI * NW > kBN && srow >= kBN) return; // (tiny head dims: fewer rows than lanes cover)
 #pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int idx = tid + i * NT;
-            if (TILE_CHUNKS % NT == 0 || idx < TILE_CHUNKS) {
-                int row;
-                char *kw, *vw;
-                if constexpr (REGULAR && RPP % 16 == 0) {
-                    row = row0 + i * RPP;
-                    kw = kw0 + i * RPP * RB;
-                    vw = vw0 + i * RPP * RB;
-                } else {
-                    row = idx / CH;
-                    const int ch = idx - row * CH;
-                    kw = sK + lds_k_off(row, ch);
-                    vw = sV + lds_v_off(row, ch);
-                }
-                if (ragged) { // uniform branch: zero the V rows past the key length
-                    if (j * kBN + row >= sk) vst[i] = u32x4{0, 0, 0, 0};
-                }
-                *(u32x4*)(kw + BUF * TILE_BYTES) = kst[i];
-                *(u32x4*)(vw + BUF * TILE_BYTES) = vst[i];
+        for (int i = 0; i < NI; ++i) {
+            const int row = i * RPI * NW; // + srow; wave-uniform part
+            const char *kg, *vg;
+            if constexpr (PAGED) {
+                const int key = min(j * kBN + row + srow, last_key);
+                const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+                const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
+                const int64_t pid = table[min(pg, a.max_blocks - 1)];
+                kg = kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row);
+                vg = vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch;
+            } else {
+                const uint32_t rows = (uint32_t)(j * kBN + row);
+                // (chunk delta of instruction i, a compile-time XOR pattern, when the K swizzle moves with i)
+                const int kd = KSWZ_FIXED ? 0 : 16 * (k_src_chunk(srow + row) - s_kch);
+                kg = kbase + min(k_go + rows * k_sb, k_gmax) + kd;
+                vg = vbase + min(v_go + rows * v_sb, v_gmax);
             }
+            char* kl = sK + BUF * TILE_BYTES + (row + wave * RPI) * RB; // wave-uniform LDS piece base
+            char* vl = sV + BUF * TILE_BYTES + (row + wave * RPI) * RB;
+            __builtin_amdgcn_global_load_lds((gptr_t)kg, (lptr_t)kl, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)vg, (lptr_t)vl, 16, 0, 0);
         }
     };
 
@@ -264,19 +250,19 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const float c = a.scale_log2;
     const int wrow0 = m0 + 32 * wave; // first query row of this wave
 
-    if (nt > 0 && sk > 0) stage_load(0);
-    // Everything loaded so far (Q fragments, tile 0) is waited for HERE: with the Q loads still on the
+    if (nt > 0 && sk > 0) stage_dma(0, std::integral_constant<int, 0>{});
+    // Everything issued so far (Q fragments, tile 0's DMA) is waited for HERE: with the Q loads still on the
     // scoreboard at the loop header, hipcc re-waits for them inside the loop (vmcnt(7..0) before the QK^T
-    // MFMAs), which from the second iteration on drains the just-issued staging loads of the next tile.
+    // MFMAs), which from the second iteration on would drain the just-issued DMA of the next tile.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-    if (nt > 0 && sk > 0) stage_write(0, std::integral_constant<int, 0>{});
     __syncthreads();
 
     // one key tile out of LDS buffer BUF (compile-time, so every LDS offset is an immediate)
     auto tile = [&](int j, auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         const bool more = j + 1 < nt;
-        if (more) stage_load(j + 1);
+        // next tile's DMA goes into the other buffer: every wave left it at the previous barrier
+        if (more && !(ABL & 1)) stage_dma(j + 1, std::integral_constant<int, BUF ^ 1>{});
 
         // a wave whose rows all precede this tile's first key has nothing to do under the causal mask
         const bool active = !a.is_causal || j * kBN <= wrow0 + 31;
@@ -333,18 +319,22 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
                 m_run = m_new;
             }
-            float psum = 0.f;
+            // p = exp2(s*c - m*c): packed fma / packed add on register pairs, one v_exp per element
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
+            f32x2 ps2 = {0.f, 0.f};
             uint32_t pk[2][8];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    const float p0 = fast_exp2(fmaf(s[kb][2 * i], c, -mc));
-                    const float p1 = fast_exp2(fmaf(s[kb][2 * i + 1], c, -mc));
-                    psum += p0 + p1;
-                    pk[kb][i] = E::pack(p0, p1);
+                    const f32x2 sv = {s[kb][2 * i], s[kb][2 * i + 1]};
+                    const f32x2 t = __builtin_elementwise_fma(sv, c2, nmc2);
+                    const f32x2 pv = (ABL & 4) ? t : f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
+                    ps2 += pv;
+                    pk[kb][i] = E::pack(pv[0], pv[1]);
                 }
-            l_run += psum;
+            l_run += ps2[0] + ps2[1];
 
             // ---- O^T += V^T . P^T : 4 k-steps of 16 keys x DB column blocks ---------------------------
 #pragma unroll
@@ -359,12 +349,14 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * RB));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
+                    if (!(ABL & 8)) oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
+                    else oacc[d][0] += (float)vv[0] + (float)vv[4];
                 }
             }
         }
-        if (more) stage_write(j + 1, std::integral_constant<int, BUF ^ 1>{});
-        __syncthreads();
+        // the DMA is a pending LDS write on the VM counter: drain it, then let the other waves read the tile
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        if (!(ABL & 2)) __syncthreads();
     };
 
     for (int j = 0; j < nt; j += 2) {
@@ -416,11 +408,30 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     constexpr int RB = Pitch<D>::RB;
     constexpr size_t smem = 4 * kBN * RB;
     a.num_m_blocks = (a.seqlen_q + BM - 1) / BM;
-    const int64_t total = (int64_t)a.num_m_blocks * a.heads * a.batch;
-    if (total <= 0) return 0;
+    const int64_t npairs = (int64_t)a.heads * a.batch;
+    if (npairs <= 0 || a.num_m_blocks <= 0) return 0;
+    static const int env_gp = [] { const char* e = getenv("MFA_GROUP_PAIRS"); return e ? atoi(e) : 0; }();
+    a.group_pairs = env_gp > 0 ? env_gp : 4;
+    // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
+    const int64_t per_xcd = (npairs + 7) / 8;
+    const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
+    const int64_t total = 8 * groups * a.group_pairs * a.num_m_blocks;
     if (total > 0x7fffffffLL) return -1;
-    a.total_blocks = (int)total;
     auto kern = prefill_fwd_kernel<T, D, NW, PAGED>;
+#ifdef MFA_ABLATION
+    if constexpr (D == 128 && !PAGED && std::is_same<T, Half>::value) {
+        static const int abl = [] { const char* e = getenv("MFA_ABLATE"); return e ? atoi(e) : 0; }();
+        switch (abl) {
+        case 1: kern = prefill_fwd_kernel<T, D, NW, PAGED, 1>; break;
+        case 3: kern = prefill_fwd_kernel<T, D, NW, PAGED, 3>; break;
+        case 4: kern = prefill_fwd_kernel<T, D, NW, PAGED, 4>; break;
+        case 8: kern = prefill_fwd_kernel<T, D, NW, PAGED, 8>; break;
+        case 7: kern = prefill_fwd_kernel<T, D, NW, PAGED, 7>; break;
+        case 15: kern = prefill_fwd_kernel<T, D, NW, PAGED, 15>; break;
+        default: break;
+        }
+    }
+#endif
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return -3;
