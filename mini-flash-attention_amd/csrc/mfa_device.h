@@ -127,4 +127,24 @@ __device__ __forceinline__ float swap32(float x) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ---- LDS-DMA: 16 bytes per lane from global memory straight into LDS (no VGPR destination) -----------------
+// The wave's 64 lanes land at lds_addr + 16*lane (lds_addr wave-uniform, in M0); the SOURCE address is per lane.
+// Issued through inline asm on purpose: with __builtin_amdgcn_global_load_lds hipcc (ROCm 7.2) treats the DMA as
+// a store that may alias every later LDS read and drains it with s_waitcnt vmcnt(0) before the first
+// ds_read_b64_tr_b16 of the tile, i.e. half a tile after it was issued.  In asm the compiler does not track it:
+// the CALLER must retire it with s_waitcnt vmcnt(N) and a workgroup barrier before any wave reads the bytes.
+// M0 is written in the same statement that consumes it and is not used by anything else in these kernels.
+__device__ __forceinline__ void lds_dma16(const char* wave_uniform_base, uint32_t lane_byte_offset, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_addr)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma16(const char* lane_ptr, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(lane_ptr), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
 } // namespace mfa

@@ -188,34 +188,36 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const uint32_t k_sb = (uint32_t)(2 * a.k_row_stride), v_sb = (uint32_t)(2 * a.v_row_stride); // row pitch, bytes
     const uint32_t k_go = srow * k_sb + 16 * s_kch, v_go = srow * v_sb + 16 * s_vch;
     const uint32_t k_gmax = last_key * k_sb + 16 * s_kch, v_gmax = last_key * v_sb + 16 * s_vch;
-    typedef __attribute__((address_space(1))) const void* gptr_t;
-    typedef __attribute__((address_space(3))) void* lptr_t;
-    auto stage_dma = [&](int j, auto bufc) {
+    // piece pc of tile j: pieces 0..NI-1 are K rows, NI..2*NI-1 are V rows
+    auto stage_piece = [&](int j, auto bufc, int pc) {
         constexpr int BUF = decltype(bufc)::value;
         if (NI * RPI * NW > kBN && srow >= kBN) return; // (tiny head dims: fewer rows than lanes cover)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int row = i * RPI * NW; // + srow; wave-uniform part
-            const char *kg, *vg;
-            if constexpr (PAGED) {
-                const int key = min(j * kBN + row + srow, last_key);
-                const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
-                const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
-                const int64_t pid = table[min(pg, a.max_blocks - 1)];
-                kg = kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row);
-                vg = vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch;
+        const bool is_v = pc >= NI;
+        const int row = (is_v ? pc - NI : pc) * RPI * NW; // + srow; wave-uniform part
+        // wave-uniform LDS piece base (readfirstlane makes the uniformity provable for the "s" operand)
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(
+            lds_address((is_v ? sV : sK) + BUF * TILE_BYTES + (row + wave * RPI) * RB));
+        if constexpr (PAGED) {
+            const int key = min(j * kBN + row + srow, last_key);
+            const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+            const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
+            const int64_t pid = table[min(pg, a.max_blocks - 1)];
+            if (is_v) lds_dma16(vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch, dst);
+            else lds_dma16(kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row), dst);
+        } else {
+            const uint32_t rows = (uint32_t)(j * kBN + row);
+            if (is_v) {
+                lds_dma16(vbase, min(v_go + rows * v_sb, v_gmax), dst);
             } else {
-                const uint32_t rows = (uint32_t)(j * kBN + row);
                 // (chunk delta of instruction i, a compile-time XOR pattern, when the K swizzle moves with i)
                 const int kd = KSWZ_FIXED ? 0 : 16 * (k_src_chunk(srow + row) - s_kch);
-                kg = kbase + min(k_go + rows * k_sb, k_gmax) + kd;
-                vg = vbase + min(v_go + rows * v_sb, v_gmax);
+                lds_dma16(kbase, min(k_go + rows * k_sb, k_gmax) + kd, dst);
             }
-            char* kl = sK + BUF * TILE_BYTES + (row + wave * RPI) * RB; // wave-uniform LDS piece base
-            char* vl = sV + BUF * TILE_BYTES + (row + wave * RPI) * RB;
-            __builtin_amdgcn_global_load_lds((gptr_t)kg, (lptr_t)kl, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)vg, (lptr_t)vl, 16, 0, 0);
         }
+    };
+    auto stage_dma = [&](int j, auto bufc) {
+#pragma unroll
+        for (int pc = 0; pc < 2 * NI; ++pc) stage_piece(j, bufc, pc);
     };
 
     // ---- per-lane LDS read addresses (bases; tile buffer, key block and k-step are immediates) ------
@@ -261,11 +263,15 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     auto tile = [&](int j, auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
         const bool more = j + 1 < nt;
-        // next tile's DMA goes into the other buffer: every wave left it at the previous barrier
-        if (more && !(ABL & 1)) stage_dma(j + 1, std::integral_constant<int, BUF ^ 1>{});
+        // The next tile's DMA goes into the other buffer (every wave left it at the previous barrier).  Its
+        // pieces are issued one per QK^T k-step, between the MFMAs, rather than as a burst: a burst of 1-KiB pieces
+        // stalls the wave at issue (the price of a piece depends on what else is in flight).
+        constexpr auto nbuf = std::integral_constant<int, BUF ^ 1>{};
+        const bool dma = more && !(ABL & 1);
 
         // a wave whose rows all precede this tile's first key has nothing to do under the causal mask
         const bool active = !a.is_causal || j * kBN <= wrow0 + 31;
+        if (!active && dma) stage_dma(j + 1, nbuf);
         if (active) {
             constexpr int kt = BUF * TILE_BYTES; // byte offset of this tile's K (and, past sK, V) buffer
             constexpr int vt = BUF * TILE_BYTES;
@@ -286,6 +292,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     for (int kb = 0; kb < 2; ++kb) kf[ks + PF][kb] = *(const frag8*)(k_rd[ks + PF] + kt + kb * 32 * RB);
                 }
                 s[0] = E::mfma32(kf[ks][0], qf[ks], s[0]);
+                if (dma) {
+#pragma unroll
+                    for (int pc = ks * 2 * NI / KS; pc < (ks + 1) * 2 * NI / KS; ++pc) stage_piece(j + 1, nbuf, pc);
+                }
                 s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
             }
             // mask: key > query row (top-left causal) or key >= sk
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             }
         }
         // the DMA is a pending LDS write on the VM counter: drain it, then let the other waves read the tile
-        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        if (!(ABL & 64)) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         if (!(ABL & 2)) __syncthreads();
     };
 
@@ -428,6 +438,9 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
         case 8: kern = prefill_fwd_kernel<T, D, NW, PAGED, 8>; break;
         case 7: kern = prefill_fwd_kernel<T, D, NW, PAGED, 7>; break;
         case 15: kern = prefill_fwd_kernel<T, D, NW, PAGED, 15>; break;
+        case 32: kern = prefill_fwd_kernel<T, D, NW, PAGED, 32>; break;
+        case 64: kern = prefill_fwd_kernel<T, D, NW, PAGED, 64>; break;
+        case 66: kern = prefill_fwd_kernel<T, D, NW, PAGED, 66>; break;
         default: break;
         }
     }
@@ -450,7 +463,10 @@ static int launch_prefill_d(PrefillArgs& a, hipStream_t stream) {
     case 32: return launch_prefill_t<T, 32, 4>(a, stream);
     case 64: return launch_prefill_t<T, 64, 4>(a, stream);
     case 96: return launch_prefill_t<T, 96, 4>(a, stream);
-    case 128: return launch_prefill_t<T, 128, 4>(a, stream);
+    case 128: {
+        static const int env_nw = [] { const char* e = getenv("MFA_NW"); return e ? atoi(e) : 0; }();
+        return env_nw == 8 ? launch_prefill_t<T, 128, 8>(a, stream) : launch_prefill_t<T, 128, 4>(a, stream);
+    }
     case 160: return launch_prefill_t<T, 160, 4>(a, stream);
     case 192: return launch_prefill_t<T, 192, 4>(a, stream);
     case 224: return launch_prefill_t<T, 224, 4>(a, stream);
