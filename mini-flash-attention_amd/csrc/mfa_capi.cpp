@@ -49,6 +49,13 @@ int check_common(const mfa_forward_params* p) {
     for (int64_t s : strides)
         if (s % 8 != 0)
             return fail(MFA_ERR_INVALID_ARGUMENT, "every q/k/v/o stride must be a multiple of 8 elements (16 bytes)");
+    // non-paged K/V rows are addressed with 32-bit byte offsets from a per-(batch, kv head) base
+    if (!p->block_table) {
+        const int64_t span_k = (int64_t)p->seqlen_k * p->k_row_stride * 2, span_v = (int64_t)p->seqlen_k * p->v_row_stride * 2;
+        const bool varlen = p->cu_seqlens_k != nullptr; // (varlen: seqlen_k is the longest sequence)
+        if (!varlen && (span_k >= (1LL << 32) || span_v >= (1LL << 32)))
+            return fail(MFA_ERR_UNSUPPORTED, "one batch element of K/V spans 4 GiB or more; use a paged cache");
+    }
     if (p->block_table) {
         if (p->page_block_size <= 0) return fail(MFA_ERR_INVALID_ARGUMENT, "page_block_size must be positive");
         if (p->max_blocks_per_seq <= 0)

@@ -58,7 +58,9 @@ struct RowBuf {
     u32x4 r[N];
 };
 
-template <typename T, int LPR, int GT>
+enum { kDense = 0, kPagedPow2 = 1, kPagedDiv = 2 };
+
+template <typename T, int LPR, int GT, int MODE>
 __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const DecodeArgs a) {
     constexpr int RPL = 64 / LPR;                          // rows per wave-instruction
     constexpr int TILE = kDecodeWaves * kUnroll * RPL;     // keys per workgroup iteration
@@ -88,10 +90,9 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     for (int g = 0; g < GT; ++g) {
         const int gq = min(g0 + g, a.group - 1);
         const char* qp = (const char*)a.q + 2 * (b * a.q_batch_stride + (int64_t)(hk * a.group + gq) * a.q_head_stride);
-        u32x4 t = {0, 0, 0, 0};
-        if (col_ok) t = *(const u32x4*)(qp + 16 * c);
+        const u32x4 t = *(const u32x4*)(qp + (col_ok ? 16 * c : 0));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) qf[g][i] = t[i];
+        for (int i = 0; i < 4; ++i) qf[g][i] = col_ok ? t[i] : 0u;
     }
 
     DecodeState<T, LPR, GT> st;
@@ -103,44 +104,42 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
         for (int i = 0; i < 8; ++i) st.acc[g][i] = 0.f;
     }
 
-    const bool paged = a.block_table != nullptr;
+    constexpr bool paged = MODE != kDense;
     const char* kbase = (const char*)a.k + 2 * ((int64_t)hk * a.k_head_stride + (paged ? 0 : b * a.k_batch_stride));
     const char* vbase = (const char*)a.v + 2 * ((int64_t)hk * a.v_head_stride + (paged ? 0 : b * a.v_batch_stride));
     const int32_t* table = paged ? a.block_table + b * a.table_batch_stride : nullptr;
+    // lanes whose 16-byte chunk lies past head_dim (D not a multiple of 8*LPR) read chunk 0 and contribute zeros
+    const int cc = col_ok ? c : 0;
+    const uint32_t cmask = col_ok ? 0xffffffffu : 0u;
 
     // key handled by (this wave, this lane group) for unroll slot u of the iteration starting at k0
     auto key_of = [&](int k0, int u) { return k0 + (u * kDecodeWaves + wave) * RPL + lg; };
 
-    // page id (or the key itself when not paged) for the clamped key
+    // Loads never branch: a key past the end of this split is clamped to its last key (a valid, finite row whose
+    // score is masked to -inf below), so over-running iterations only re-read one cached row.
+    // page id for the clamped key (paged), looked up one iteration ahead of the row loads that need it
     auto page_lookup = [&](int key) -> int {
+        if constexpr (!paged) return 0;
         key = min(key, kend - 1);
-        if (!paged) return key;
-        const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+        const int pg = MODE == kPagedPow2 ? (key >> a.page_shift) : (key / a.page_size);
         return table[min(pg, a.max_blocks - 1)];
     };
-    auto row_offsets = [&](int key, int pid, int64_t& ko, int64_t& vo) {
-        key = min(key, kend - 1);
-        if (!paged) {
-            ko = (int64_t)key * a.k_row_stride;
-            vo = (int64_t)key * a.v_row_stride;
-        } else {
-            const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key % a.page_size);
-            ko = (int64_t)pid * a.k_block_stride + (int64_t)in * a.k_row_stride;
-            vo = (int64_t)pid * a.v_block_stride + (int64_t)in * a.v_row_stride;
-        }
-    };
-
     auto load_rows = [&](RowBuf<kUnroll>& kb, RowBuf<kUnroll>& vb, int k0, const int (&pid)[kUnroll]) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            int64_t ko, vo;
-            row_offsets(key_of(k0, u), pid[u], ko, vo);
-            u32x4 z = {0, 0, 0, 0};
-            kb.r[u] = z;
-            vb.r[u] = z;
-            if (col_ok) {
-                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kbase + 2 * ko + 16 * c));
-                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vbase + 2 * vo + 16 * c));
+            const int key = min(key_of(k0, u), kend - 1);
+            if constexpr (!paged) {
+                // 32-bit byte offsets on a wave-uniform base (one (batch, kv head) slab is < 4 GiB)
+                const uint32_t ko = (uint32_t)key * (uint32_t)(2 * a.k_row_stride) + 16 * cc;
+                const uint32_t vo = (uint32_t)key * (uint32_t)(2 * a.v_row_stride) + 16 * cc;
+                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kbase + ko));
+                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vbase + vo));
+            } else {
+                const int in = MODE == kPagedPow2 ? (key & (a.page_size - 1)) : (key % a.page_size);
+                const int64_t ko = (int64_t)pid[u] * a.k_block_stride + (int64_t)in * a.k_row_stride;
+                const int64_t vo = (int64_t)pid[u] * a.v_block_stride + (int64_t)in * a.v_row_stride;
+                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kbase + 2 * ko + 16 * cc));
+                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vbase + 2 * vo + 16 * cc));
             }
         }
     };
@@ -180,8 +179,9 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
                 float a0 = st.acc[g][2 * i] * alpha, a1 = st.acc[g][2 * i + 1] * alpha;
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
-                    a0 = fmaf(p[u], Elem<T>::lo(vb.r[u][i]), a0);
-                    a1 = fmaf(p[u], Elem<T>::hi(vb.r[u][i]), a1);
+                    const uint32_t w = vb.r[u][i] & cmask;
+                    a0 = fmaf(p[u], Elem<T>::lo(w), a0);
+                    a1 = fmaf(p[u], Elem<T>::hi(w), a1);
                 }
                 st.acc[g][2 * i] = a0;
                 st.acc[g][2 * i + 1] = a1;
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     };
 
     if (kbeg < kend) {
+        // two register buffers, iterations taken in pairs; every load and compute of the pair is unconditional
         RowBuf<kUnroll> kA, vA, kB, vB;
         int pid[kUnroll], pidn[kUnroll];
 #pragma unroll
@@ -197,16 +198,22 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
         load_rows(kA, vA, kbeg, pid);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg + TILE, u));
+        // sched_barrier: without it hipcc's scheduler, chasing occupancy, sinks every load down to its first use
+        // (load; s_waitcnt vmcnt(0); use), which serialises the whole stream.  The loads of the NEXT buffer must
+        // issue before the compute on the CURRENT one.
         for (int k0 = kbeg; k0 < kend; k0 += 2 * TILE) {
-            const bool has1 = k0 + TILE < kend, has2 = k0 + 2 * TILE < kend;
-            if (has1) load_rows(kB, vB, k0 + TILE, pid);
+            load_rows(kB, vB, k0 + TILE, pid);
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) pidn[u] = page_lookup(key_of(k0 + 2 * TILE, u));
+            __builtin_amdgcn_sched_barrier(0);
             compute(kA, vA, k0);
-            if (has2) load_rows(kA, vA, k0 + 2 * TILE, pidn);
+            __builtin_amdgcn_sched_barrier(0);
+            load_rows(kA, vA, k0 + 2 * TILE, pidn);
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(k0 + 3 * TILE, u));
-            if (has1) compute(kB, vB, k0 + TILE);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(kB, vB, k0 + TILE);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -312,7 +319,12 @@ template <typename T, int LPR, int GT>
 static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
     dim3 grid(a.num_splits, a.kv_heads * a.nchunks, a.batch);
     const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
-    hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT>), grid, dim3(kDecodeThreads), smem, stream, a);
+    if (!a.block_table)
+        hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kDense>), grid, dim3(kDecodeThreads), smem, stream, a);
+    else if (a.page_shift >= 0)
+        hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedPow2>), grid, dim3(kDecodeThreads), smem, stream, a);
+    else
+        hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedDiv>), grid, dim3(kDecodeThreads), smem, stream, a);
     if (a.num_splits > 1) {
         const int rows_per_block = 256 / a.head_dim > 0 ? 256 / a.head_dim : 1;
         const int64_t BH = (int64_t)a.batch * a.heads;
