@@ -92,22 +92,27 @@ int mfa_device_cu_count(int device) {
     return n;
 }
 
-// The reference sizes its split count from batch*QUERY heads on 2*SMs (api.cpp:269-302).  The native
-// kernel runs one workgroup per (batch, KV head, split), so the count is re-derived from batch*kv_heads:
-// aim at ~4 workgroups of 256 threads per CU, never cut a split below 4 tiles of 64 keys, and keep the
-// splits even.  Only the ARGUMENT semantics are the reference's: <1 = auto, explicit values are clamped
-// to the number of 64-key tiles (api.cpp:320-327).
+// The reference sizes its split count from batch*QUERY heads on 2*SMs (api.cpp:269-302).  The native kernel runs
+// one workgroup per (batch, KV head, split) and every wave keeps 16 KiB of loads in flight, so it saturates HBM
+// with well under one workgroup per CU: measured on MI355X (tools/split_sweep.py) the best total is ~0.5-1
+// workgroup per CU, and splitting beyond that only adds combine work.  Rule: no split once batch*kv_heads reaches
+// 3/4 of the CUs; otherwise enough splits to reach that many workgroups, never below 4 tiles of 64 keys per
+// split, evened out.  Only the ARGUMENT semantics are the reference's: <1 = auto, explicit values are clamped to
+// the number of 64-key tiles (api.cpp:320-327).
 int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_k, int num_cus) {
     const int ntiles = (seqlen_k + 63) / 64;
     if (ntiles <= 1) return 1;
-    if (requested >= 1) return requested > ntiles ? ntiles : requested;
+    if (requested >= 1) { // explicit: clamp to the tile count (api.cpp:325-327) and to the combine kernel's 128
+        const int lim = ntiles < 128 ? ntiles : 128;
+        return requested > lim ? lim : requested;
+    }
     if (num_cus <= 0) {
         num_cus = mfa_device_cu_count(-1);
         if (num_cus <= 0) num_cus = 256;
     }
     const long base = static_cast<long>(batch) * kv_heads;
     if (base <= 0) return 1;
-    const long target = 4L * num_cus;
+    const long target = (3L * num_cus + 3) / 4;
     if (base >= target) return 1;
     long splits = (target + base - 1) / base;
     const long max_splits = ntiles / 4 > 1 ? ntiles / 4 : 1;
@@ -147,6 +152,8 @@ int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip
     if (int rc = check_common(p)) return rc;
     if (p->seqlen_q != 1)
         return fail(MFA_ERR_INVALID_ARGUMENT, "flash decoding expects seqlen_q == 1, got %d", p->seqlen_q);
+    if (p->num_splits > 128)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "num_splits must be <= 128 (got %d); see mfa_num_splits_heuristic", p->num_splits);
     if (p->num_splits > 1 && (!p->softmax_lseaccum_ptr || !p->oaccum_ptr))
         return fail(MFA_ERR_WORKSPACE, "num_splits=%d needs softmax_lseaccum_ptr and oaccum_ptr", p->num_splits);
     // O may be strided: the combine kernel honours o_*_stride (the reference assumes contiguous, decode.cuh:730)

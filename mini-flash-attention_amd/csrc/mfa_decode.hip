@@ -288,31 +288,52 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     }
 }
 
-// O = sum_s o_s * exp(lse_s - LSE), LSE = ln sum_s exp(lse_s)  (decode.cuh:718-747, max-subtracted)
+// O = sum_s o_s * exp(lse_s - LSE), LSE = ln sum_s exp(lse_s)  (decode.cuh:718-747, max-subtracted).
+// One workgroup per (batch, head): the split weights go through LDS once, then the 256 threads cover
+// (split lane, column) so the partial-O reads of different splits are in flight together.
 template <typename T>
 __global__ __launch_bounds__(256) void decode_combine_kernel(const DecodeArgs a) {
-    const int D = a.head_dim;
+    __shared__ float w_sh[128];      // exp(lse_s - M)
+    __shared__ float red[256];
+    __shared__ float stat[2];        // M, W
+    const int D = a.head_dim, S = a.num_splits;
     const int64_t BH = (int64_t)a.batch * a.heads;
-    // one (batch, head) row per D-thread slice of the block
-    const int rows_per_block = 256 / min(D, 256);
-    const int64_t bh = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / D;
-    const int d = threadIdx.x % D;
-    if (bh >= BH || threadIdx.x >= rows_per_block * D) return;
-    float M = -INFINITY;
-    for (int s = 0; s < a.num_splits; ++s) M = fmaxf(M, a.lse_acc[s * BH + bh]);
-    float W = 0.f, o = 0.f;
-    if (M != -INFINITY) {
-        for (int s = 0; s < a.num_splits; ++s) {
-            const float w = __expf(a.lse_acc[s * BH + bh] - M);
-            W += w;
-            o += w * a.o_acc[(s * BH + bh) * D + d];
-        }
-        o /= W;
+    const int64_t bh = blockIdx.x;
+    const int tid = threadIdx.x;
+    const float lse_t = tid < S ? a.lse_acc[tid * BH + bh] : -INFINITY;
+    // max over the splits (S <= 128: two waves)
+    float m = lse_t;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    const float M = fmaxf(red[0], red[1]);
+    const float w = (tid < S && M != -INFINITY) ? __expf(lse_t - M) : 0.f;
+    if (tid < 128) w_sh[tid] = w;
+    float ws = w;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ws += __shfl_xor(ws, off);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = ws;
+    __syncthreads();
+    const float W = red[0] + red[1];
+    __syncthreads();
+    // thread (sl, d): splits sl, sl + SL, ... of column d
+    const int SL = 256 / D > 0 ? 256 / D : 1;
+    const int d = tid % D, sl = tid / D;
+    float o = 0.f;
+    if (sl < SL)
+        for (int s = sl; s < S; s += SL) o += w_sh[s] * a.o_acc[(s * BH + bh) * D + d];
+    red[tid] = o;
+    __syncthreads();
+    if (tid < D) {
+        for (int k = 1; k < SL; ++k) o += red[k * D + tid];
+        o = W > 0.f ? o / W : 0.f;
+        const int b = bh / a.heads, h = bh % a.heads;
+        char* op = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)h * a.o_head_stride + tid);
+        *(uint16_t*)op = (uint16_t)Elem<T>::pack(o, 0.f);
+        if (tid == 0 && a.lse) a.lse[bh] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
     }
-    const int b = bh / a.heads, h = bh % a.heads;
-    char* op = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)h * a.o_head_stride + d);
-    *(uint16_t*)op = (uint16_t)Elem<T>::pack(o, 0.f);
-    if (d == 0 && a.lse) a.lse[bh] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
 }
 
 template <typename T, int LPR, int GT>
@@ -326,10 +347,8 @@ static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
     else
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedDiv>), grid, dim3(kDecodeThreads), smem, stream, a);
     if (a.num_splits > 1) {
-        const int rows_per_block = 256 / a.head_dim > 0 ? 256 / a.head_dim : 1;
         const int64_t BH = (int64_t)a.batch * a.heads;
-        dim3 cgrid((unsigned)((BH + rows_per_block - 1) / rows_per_block));
-        hipLaunchKernelGGL((decode_combine_kernel<T>), cgrid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((decode_combine_kernel<T>), dim3((unsigned)BH), dim3(256), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
