@@ -15,6 +15,8 @@
 //     correct (the reference resolves once per 64-key tile: decode.cuh:50-55).
 // Numerics follow decode.cuh:296-312 (fp32 dot), :367-383 (online softmax in the log2 domain, P kept
 // fp32), :587-661 (merge, LSE = M*scale + ln L), :718-747 (combine, here max-subtracted).
+#include <cstdlib>
+
 #include "mfa_device.h"
 #include "mfa_launch.h"
 
@@ -174,17 +176,18 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
                 ps += p[u];
             }
             st.l[g] = st.l[g] * alpha + ps;
+            // acc[g] = acc[g]*alpha + sum_u p[u] * v[u]  on register pairs (v_pk_mul_f32 / v_pk_fma_f32)
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float a0 = st.acc[g][2 * i] * alpha, a1 = st.acc[g][2 * i + 1] * alpha;
+                f32x2 acc2 = f32x2{st.acc[g][2 * i], st.acc[g][2 * i + 1]} * f32x2{alpha, alpha};
 #pragma unroll
                 for (int u = 0; u < kUnroll; ++u) {
                     const uint32_t w = vb.r[u][i] & cmask;
-                    a0 = fmaf(p[u], Elem<T>::lo(w), a0);
-                    a1 = fmaf(p[u], Elem<T>::hi(w), a1);
+                    acc2 = __builtin_elementwise_fma(f32x2{p[u], p[u]}, f32x2{Elem<T>::lo(w), Elem<T>::hi(w)}, acc2);
                 }
-                st.acc[g][2 * i] = a0;
-                st.acc[g][2 * i + 1] = a1;
+                st.acc[g][2 * i] = acc2[0];
+                st.acc[g][2 * i + 1] = acc2[1];
             }
         }
     };
@@ -393,8 +396,16 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
     a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
     a.scale_log2 = p.softmax_scale_log2;
     const int G = a.group;
+    static const int env_gtmax = [] { const char* e = getenv("MFA_DECODE_GT_MAX"); return e ? atoi(e) : 0; }();
+    const int gtmax = env_gtmax > 0 ? env_gtmax : 8;
     int gt = G <= 4 ? G : (G <= 6 ? 6 : 8);
     if (G == 5) gt = 6;
+    if (gt > gtmax) { // split the group evenly over ceil(G / gtmax) workgroups
+        const int nch = (G + gtmax - 1) / gtmax;
+        gt = (G + nch - 1) / nch;
+        if (gt == 5) gt = 6;
+        if (gt == 7) gt = 8;
+    }
     a.nchunks = (G + gt - 1) / gt;
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
 }
