@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 1
+#define MFA_ABI_VERSION 2
 
 enum {
     MFA_OK = 0,
@@ -88,25 +88,57 @@ typedef struct mfa_forward_params {
     int64_t k_cache_block_stride; /* elements between pages                                    */
     int64_t v_cache_block_stride;
 
-    const int32_t* seqlens_k; /* decode: (B) valid cache length, NULL = seqlen_k for every b    */
+    const int32_t* seqlens_k; /* kv-cache: (B) valid cache length, NULL = seqlen_k for every b (decode; also
+                                 honoured by the forward entry when cu_seqlens_k is NULL: Sq > 1 on a cache)   */
 
     int32_t num_splits; /* decode: <1 = choose (mfa_num_splits_heuristic), 1 = no split        */
 
-    float* softmax_lse_ptr;      /* decode: (B,H) fp32, natural-log LSE; may be NULL           */
+    float* softmax_lse_ptr;      /* natural-log LSE out, may be NULL. decode: (B,H); prefill: dense (B,H,Sq),
+                                    varlen (H,total_q) (the reference computes it for decode only and drops it) */
     float* softmax_lseaccum_ptr; /* decode split: (S,B,H) fp32 workspace                       */
     float* oaccum_ptr;           /* decode split: (S,B,H,D) fp32 workspace                     */
 
-    /* additive fields */
+    /* additive fields (all "off" when zero, so a zero-initialised struct behaves like the reference) */
     int32_t max_blocks_per_seq; /* paged: columns of block_table (bounds the table reads)      */
     int32_t num_cus;            /* 0 = query the device                                        */
+    int32_t mask_bottom_right;  /* causal / window aligned to the LAST key (offset sk - sq, flash-attn >= 2.1)
+                                   instead of the reference's top-left; used by kv-cache attention with Sq > 1 */
+    int32_t use_local_window;   /* 1: apply local_window_left/right (sliding-window attention); the reference's
+                                   window_size_* fields above stay accepted-and-ignored, as upstream         */
+    int32_t local_window_left;  /* keys >= row + off - left  (-1 = unbounded)                  */
+    int32_t local_window_right; /* keys <= row + off + right (-1 = unbounded)                  */
+    int64_t total_q;            /* varlen: rows of q (layout of the LSE output)                */
+    int32_t seqlens_k_offset;   /* added to every seqlens_k[b] (keys just appended by mfa_kvcache_append)     */
     int32_t reserved;
 } mfa_forward_params;
+
+/* KV-cache append: copy new K/V rows (B, Sn, Hkv, D) into the cache at positions seqlens_k[b] .. +Sn-1 (dense
+ * (B,Sk,Hkv,D) cache or paged (num_blocks,page,Hkv,D) + block_table).  Not in the reference: its docstring promises
+ * it (mini_flash_attention/interface.py:110-111) and its tests do it in Python (tests/test_flash_decoding.py:574-597);
+ * semantics are flash-attn's `flash_attn_with_kvcache(k=, v=)`.  Rows that would land past the cache capacity are
+ * dropped.  Strides in elements. */
+typedef struct mfa_kvcache_append_params {
+    const void* k_new; const void* v_new;   /* (B, Sn, Hkv, D) */
+    void* k_cache; void* v_cache;
+    int64_t kn_batch_stride, kn_row_stride, kn_head_stride;
+    int64_t vn_batch_stride, vn_row_stride, vn_head_stride;
+    int64_t kc_batch_stride, kc_row_stride, kc_head_stride; /* dense: batch stride; paged: block stride */
+    int64_t vc_batch_stride, vc_row_stride, vc_head_stride;
+    const int32_t* seqlens_k;   /* (B) position of the first new row; NULL = 0                                */
+    const int32_t* block_table; /* (B, max_blocks) or NULL                                                    */
+    int64_t block_table_batch_stride;
+    int32_t batch, seqlen_new, kv_heads, head_dim;
+    int32_t seqlen_k;           /* dense: cache rows per batch element; paged: max_blocks * page_block_size   */
+    int32_t page_block_size, max_blocks_per_seq;
+    int32_t is_bf16;            /* (only the element size matters: 2 bytes either way)                        */
+} mfa_kvcache_append_params;
 
 /* ABI / build identification. */
 int mfa_abi_version(void);
 const char* mfa_version(void);
 const char* mfa_last_error(void);
 size_t mfa_forward_params_sizeof(void); /* sizeof(mfa_forward_params) the library was built with */
+size_t mfa_kvcache_append_params_sizeof(void);
 
 /* softmax_scale = 1/sqrt(head_dim), softmax_scale_log2 = softmax_scale*log2(e); kv_group_size. */
 void mfa_forward_params_set_scale(mfa_forward_params* p);
@@ -117,6 +149,9 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
 /* Decode (seqlen_q == 1) forward with optional split-KV + LSE combine.
  * p->num_splits must already be resolved (>= 1); workspaces must be present when it is > 1. */
 int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream);
+
+/* Append new K/V rows to the cache (see mfa_kvcache_append_params). */
+int mfa_kvcache_append(const mfa_kvcache_append_params* p, void* hip_stream);
 
 /* Split count the decode path would choose for this problem on a device with `num_cus` CUs
  * (0 = query the current device).  `requested` < 1 means "auto"; an explicit request is only

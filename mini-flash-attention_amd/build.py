@@ -58,7 +58,7 @@ def torch_lib_dir():
 
 def build_hip_lib(force=False):
     os.makedirs(BUILD, exist_ok=True)
-    srcs = ["mfa_prefill.hip", "mfa_decode.hip", "mfa_capi.cpp"]
+    srcs = ["mfa_prefill.hip", "mfa_decode.hip", "mfa_kvcache.hip", "mfa_capi.cpp"]
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
@@ -67,7 +67,7 @@ def build_hip_lib(force=False):
         if force or _stale(obj, [src] + _headers()):
             cmd = [HIPCC] + HIP_FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
             jobs.append(cmd)
-    with ThreadPoolExecutor(max_workers=3) as ex:
+    with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(_run, jobs))
     out = os.path.join(PKG, "libmfa_hip.so")
     if force or jobs or _stale(out, objs):

@@ -76,6 +76,30 @@ const char* mfa_last_error(void) { return g_err; }
 
 size_t mfa_forward_params_sizeof(void) { return sizeof(mfa_forward_params); }
 
+size_t mfa_kvcache_append_params_sizeof(void) { return sizeof(mfa_kvcache_append_params); }
+
+int mfa_kvcache_append(const mfa_kvcache_append_params* p, void* hip_stream) {
+    if (!p) return fail(MFA_ERR_INVALID_ARGUMENT, "params is NULL");
+    if (!p->k_new || !p->v_new || !p->k_cache || !p->v_cache)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "k_new, v_new, k_cache and v_cache must be non-NULL");
+    if (p->head_dim <= 0 || p->head_dim % 8 != 0 || p->head_dim > 256)
+        return fail(MFA_ERR_UNSUPPORTED, "head_dim must be a multiple of 8, at most 256 (got %d)", p->head_dim);
+    if (p->batch < 0 || p->seqlen_new < 0 || p->kv_heads <= 0 || p->seqlen_k < 0)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "negative or zero size");
+    if (!aligned16(p->k_new) || !aligned16(p->v_new) || !aligned16(p->k_cache) || !aligned16(p->v_cache))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "k_new, v_new, k_cache, v_cache must be 16-byte aligned");
+    const int64_t strides[] = {p->kn_batch_stride, p->kn_row_stride, p->kn_head_stride, p->vn_batch_stride,
+                               p->vn_row_stride,   p->vn_head_stride, p->kc_batch_stride, p->kc_row_stride,
+                               p->kc_head_stride,  p->vc_batch_stride, p->vc_row_stride, p->vc_head_stride};
+    for (int64_t s : strides)
+        if (s % 8 != 0) return fail(MFA_ERR_INVALID_ARGUMENT, "every stride must be a multiple of 8 elements (16 bytes)");
+    if (p->block_table && (p->page_block_size <= 0 || p->max_blocks_per_seq <= 0))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "page_block_size and max_blocks_per_seq must be set with a block_table");
+    if (mfa::launch_kvcache_append(*p, static_cast<hipStream_t>(hip_stream)))
+        return fail(MFA_ERR_LAUNCH, "kvcache append launch failed: %s", hipGetErrorString(hipGetLastError()));
+    return MFA_OK;
+}
+
 void mfa_forward_params_set_scale(mfa_forward_params* p) {
     if (!p || p->head_dim <= 0) return;
     // reference: csrc/mfa/api.cpp:84, 99-100
@@ -139,6 +163,10 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
     if (int rc = check_common(p)) return rc;
     if (p->head_dim % 32 != 0)
         return fail(MFA_ERR_UNSUPPORTED, "prefill supports head_dim in {32,64,...,256} (got %d)", p->head_dim);
+    if (p->use_local_window && (p->local_window_left < -1 || p->local_window_right < -1))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "local_window_left/right must be >= -1");
+    if (p->softmax_lse_ptr && p->cu_seqlens_q && p->total_q <= 0)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "total_q must be set to return the LSE of a varlen batch");
     if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr))
         return fail(MFA_ERR_INVALID_ARGUMENT, "cu_seqlens_q and cu_seqlens_k must be given together");
     if (p->batch == 0 || p->seqlen_q == 0) return MFA_OK;

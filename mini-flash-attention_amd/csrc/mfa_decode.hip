@@ -41,6 +41,7 @@ struct DecodeArgs {
     int32_t page_size, page_shift; // page_shift >= 0 when page_size is a power of two
     int32_t max_blocks;
     int32_t num_splits, nchunks;
+    int32_t seqlens_k_offset; // added to seqlens_k[b] (rows appended just before this launch)
     float scale_log2; // softmax_scale * log2(e)
 };
 
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     const int b = blockIdx.z;
     const int g0 = chunk * GT; // first query head (within the group) of this workgroup
 
-    int len = a.seqlens_k ? a.seqlens_k[b] : a.seqlen_k;
+    int len = a.seqlens_k ? a.seqlens_k[b] + a.seqlens_k_offset : a.seqlen_k;
     len = min(max(len, 0), a.seqlen_k);
     // split ranges in units of 64-key tiles (decode.cuh:26-30)
     const int ntiles = (len + 63) >> 6;
@@ -395,6 +396,7 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
     a.max_blocks = p.max_blocks_per_seq > 0 ? p.max_blocks_per_seq : (p.seqlen_k + a.page_size - 1) / a.page_size;
     a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
     a.scale_log2 = p.softmax_scale_log2;
+    a.seqlens_k_offset = p.seqlens_k_offset;
     const int G = a.group;
     static const int env_gtmax = [] { const char* e = getenv("MFA_DECODE_GT_MAX"); return e ? atoi(e) : 0; }();
     const int gtmax = env_gtmax > 0 ? env_gtmax : 8;

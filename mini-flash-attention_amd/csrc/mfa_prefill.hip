@@ -46,6 +46,15 @@ struct PrefillArgs {
     int32_t group_pairs; // (batch, head) pairs per scheduling group
     int32_t is_causal;
     float scale_log2;
+    // widening beyond the reference's surface (all off when zero / null):
+    const int32_t* seqlens_k; // dense or paged K cache with a per-batch valid length (kv-cache attention, Sq > 1)
+    float* lse;               // natural-log LSE out: dense (B,H,Sq), varlen (H,total_q); null = not wanted
+    int64_t total_q;
+    int32_t has_hi, hi_off;   // keep key <= row + off + hi_off   (causal: has_hi = 1, hi_off = 0)
+    int32_t has_lo, lo_off;   // keep key >= row + off + lo_off   (sliding window: lo_off = -window_left)
+    int32_t seqlens_k_offset; // added to seqlens_k[b]
+    int32_t bottom_right;     // off = sk - sq (flash-attn >= 2.1 alignment) instead of 0 (the reference's top-left)
+    float scale;              // softmax_scale (for the LSE)
 };
 
 constexpr int kBN = 64; // keys per tile
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         v_off = a.block_table ? 0 : (int64_t)k0 * a.v_row_stride;
     } else {
         sq = a.seqlen_q;
-        sk = a.seqlen_k;
+        sk = a.seqlens_k ? min(max(a.seqlens_k[b] + a.seqlens_k_offset, 0), a.seqlen_k) : a.seqlen_k;
         q_off = b * a.q_batch_stride;
         o_off = b * a.o_batch_stride;
         k_off = a.block_table ? 0 : b * a.k_batch_stride;
@@ -150,9 +159,20 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     char* obase = (char*)a.o + 2 * (o_off + (int64_t)hq * a.o_head_stride);
     const int32_t* table = a.block_table ? a.block_table + b * a.table_batch_stride : nullptr;
 
-    // key tiles this workgroup visits (causal range clamped to the key length)
-    int nt = (sk + kBN - 1) / kBN;
-    if (a.is_causal) nt = min(nt, (min(m0 + BM, sq) + kBN - 1) / kBN);
+    // key window of query row r: [r + lo, r + hi] intersected with [0, sk)  (top-left: off = 0, the reference's
+    // alignment, prefill.cuh:416-419; bottom-right: off = sk - sq)
+    const int off = a.bottom_right ? sk - sq : 0;
+    const bool has_hi = a.has_hi, has_lo = a.has_lo;
+    const int hi = off + a.hi_off, lo = off + a.lo_off;
+    // key tiles this workgroup visits: [j_lo, j_lo + nt)
+    int j_lo = 0, nt;
+    {
+        const int last_row = min(m0 + BM, sq) - 1;
+        const int hi_key = has_hi ? min(sk - 1, last_row + hi) : sk - 1;
+        const int j_hi = hi_key >= 0 ? hi_key / kBN + 1 : 0;
+        if (has_lo) j_lo = min(max(m0 + lo, 0) / kBN, j_hi);
+        nt = j_hi - j_lo;
+    }
 
     // ---- Q fragments (B operand of S^T = K.Q^T): row m0+32*wave+r, columns 16*ks + 8h .. +7 -------
     const int qrow = m0 + 32 * wave + r;
@@ -252,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const float c = a.scale_log2;
     const int wrow0 = m0 + 32 * wave; // first query row of this wave
 
-    if (nt > 0 && sk > 0) stage_dma(0, std::integral_constant<int, 0>{});
+    if (nt > 0 && sk > 0) stage_dma(j_lo, std::integral_constant<int, 0>{});
     // Everything issued so far (Q fragments, tile 0's DMA) is waited for HERE: with the Q loads still on the
     // scoreboard at the loop header, hipcc re-waits for them inside the loop (vmcnt(7..0) before the QK^T
     // MFMAs), which from the second iteration on would drain the just-issued DMA of the next tile.
@@ -260,17 +280,18 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     __syncthreads();
 
     // one key tile out of LDS buffer BUF (compile-time, so every LDS offset is an immediate)
-    auto tile = [&](int j, auto bufc) {
+    auto tile = [&](int jj, auto bufc) {
         constexpr int BUF = decltype(bufc)::value;
-        const bool more = j + 1 < nt;
+        const int j = j_lo + jj; // key tile index; jj counts from this block's first tile (buffer parity)
+        const bool more = jj + 1 < nt;
         // The next tile's DMA goes into the other buffer (every wave left it at the previous barrier).  Its
         // pieces are issued one per QK^T k-step, between the MFMAs, rather than as a burst: a burst of 1-KiB pieces
         // stalls the wave at issue (the price of a piece depends on what else is in flight).
         constexpr auto nbuf = std::integral_constant<int, BUF ^ 1>{};
         const bool dma = more && !(ABL & 1);
 
-        // a wave whose rows all precede this tile's first key has nothing to do under the causal mask
-        const bool active = !a.is_causal || j * kBN <= wrow0 + 31;
+        // a wave none of whose rows can see this tile (above the causal diagonal / outside the window) skips it
+        const bool active = (!has_hi || j * kBN <= wrow0 + 31 + hi) && (!has_lo || j * kBN + kBN - 1 >= wrow0 + lo);
         if (!active && dma) stage_dma(j + 1, nbuf);
         if (active) {
             constexpr int kt = BUF * TILE_BYTES; // byte offset of this tile's K (and, past sK, V) buffer
@@ -298,16 +319,25 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 }
                 s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
             }
-            // mask: key > query row (top-left causal) or key >= sk
-            const bool need_mask = (a.is_causal && j * kBN + kBN - 1 > wrow0) || (j + 1) * kBN > sk;
+            // mask: key > row + hi (causal: hi = 0, top-left) or key >= sk; register i of block kb is key
+            // j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
+            const bool need_mask = (has_hi && j * kBN + kBN - 1 > wrow0 + hi) || (j + 1) * kBN > sk;
             if (need_mask) {
-                // keys <= lim stay; register i of block kb is key j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
-                const int lim = (a.is_causal ? min(qrow, sk - 1) : sk - 1) - j * kBN - 4 * h;
+                const int lim = (has_hi ? min(qrow + hi, sk - 1) : sk - 1) - j * kBN - 4 * h; // keys <= lim stay
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                     for (int i = 0; i < 16; ++i)
                         if (32 * kb + (i & 3) + 8 * (i >> 2) > lim) s[kb][i] = -INFINITY;
+            }
+            // sliding window: key < row + lo
+            if (has_lo && j * kBN < wrow0 + 31 + lo) {
+                const int liml = qrow + lo - j * kBN - 4 * h; // keys >= liml stay
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (32 * kb + (i & 3) + 8 * (i >> 2) < liml) s[kb][i] = -INFINITY;
             }
             // ---- online softmax, all in this lane's registers ---------------------------------------
             float mt = s[0][0];
@@ -377,6 +407,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
     const float l_tot = l_run + swap32(l_run);
     const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
+    if (a.lse && h == 0 && qrow < sq) { // natural-log LSE of the scaled scores; -inf for a row that saw no key
+        const float lse = l_tot > 0.f ? m_run * a.scale + __logf(l_tot) : -INFINITY;
+        const int64_t idx = a.cu_q ? (int64_t)hq * a.total_q + a.cu_q[b] + qrow
+                                   : ((int64_t)b * a.heads + hq) * a.seqlen_q + qrow;
+        a.lse[idx] = lse;
+    }
     // the loop's last barrier guarantees every wave is done with the K/V buffers
     char* so = smem + wave * 32 * RB; // this wave's 32 rows x RB bytes
 #pragma unroll
@@ -492,6 +528,21 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     a.max_blocks = p.max_blocks_per_seq > 0 ? p.max_blocks_per_seq : 0x7fffffff;
     a.is_causal = p.is_causal;
     a.scale_log2 = p.softmax_scale_log2;
+    a.scale = p.softmax_scale;
+    a.seqlens_k = p.cu_seqlens_k ? nullptr : p.seqlens_k;
+    a.seqlens_k_offset = p.seqlens_k_offset;
+    a.lse = p.softmax_lse_ptr;
+    a.total_q = p.total_q;
+    a.bottom_right = p.mask_bottom_right;
+    // effective key window: causal closes the right side at the diagonal; the opt-in local window (not the
+    // reference's window_size_* fields, which it accepts and ignores) narrows either side
+    int wl = -1, wr = p.is_causal ? 0 : -1;
+    if (p.use_local_window) {
+        wl = p.local_window_left;
+        if (p.local_window_right >= 0) wr = wr < 0 ? p.local_window_right : (p.local_window_right < wr ? p.local_window_right : wr);
+    }
+    a.has_hi = wr >= 0; a.hi_off = wr >= 0 ? wr : 0;
+    a.has_lo = wl >= 0; a.lo_off = wl >= 0 ? -wl : 0;
     return p.is_bf16 ? launch_prefill_d<BFloat>(a, stream) : launch_prefill_d<Half>(a, stream);
 }
 

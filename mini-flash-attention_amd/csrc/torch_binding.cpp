@@ -9,6 +9,7 @@
 #include <torch/extension.h>
 
 #include <optional>
+#include <tuple>
 
 #include "mfa.h"
 
@@ -258,6 +259,218 @@ at::Tensor mha_fwd_kvcache(const at::Tensor& q, const at::Tensor& k_cache, const
     return out;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Extended entry points: the SURVEY.md §8(f) "next" rows, opt-in supersets of the reference's three functions.
+//   * sliding-window (local) attention: keys in [row + off - left, row + off + right]
+//   * the natural-log LSE as a second output
+//   * kv-cache attention with new-token append (k=, v=) and seqlen_q > 1 (bottom-right aligned causal)
+// The reference-ABI functions above are untouched (they accept and ignore window sizes, as upstream).
+// ---------------------------------------------------------------------------------------------------------------
+using OutLse = std::tuple<at::Tensor, std::optional<at::Tensor>>;
+
+void set_extras(mfa_forward_params& p, int window_left, int window_right, bool bottom_right) {
+    TORCH_CHECK(window_left >= -1 && window_right >= -1, "window sizes must be >= -1 (-1 = unbounded)");
+    if (window_left >= 0 || window_right >= 0) {
+        p.use_local_window = 1;
+        p.local_window_left = window_left;
+        p.local_window_right = window_right;
+    }
+    p.mask_bottom_right = bottom_right;
+}
+
+OutLse forward_ex(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, std::optional<at::Tensor> out_,
+                  bool is_causal, int window_left, int window_right, bool bottom_right, bool return_lse) {
+    check_dtypes(q, k, v);
+    c10::DeviceGuard guard(q.device());
+    TORCH_CHECK(q.dim() == 4 && k.dim() == 4 && v.dim() == 4, "q, k, v must be 4-D (batch, seqlen, heads, head_dim)");
+    const int batch = q.size(0), seqlen_q = q.size(1), num_heads = q.size(2), head_dim = q.size(3);
+    const int seqlen_k = k.size(1), kv_num_heads = k.size(2);
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    MFA_CHECK_SHAPE(q, batch, seqlen_q, num_heads, head_dim);
+    MFA_CHECK_SHAPE(k, batch, seqlen_k, kv_num_heads, head_dim);
+    MFA_CHECK_SHAPE(v, batch, seqlen_k, kv_num_heads, head_dim);
+    at::Tensor out;
+    if (out_.has_value()) {
+        out = out_.value();
+        TORCH_CHECK(out.scalar_type() == q.scalar_type() && out.is_cuda() && out.stride(-1) == 1, "bad out tensor");
+        MFA_CHECK_SHAPE(out, batch, seqlen_q, num_heads, head_dim);
+    } else {
+        out = at::empty_like(q);
+    }
+    mfa_forward_params p{};
+    set_tensor_strides(p, q, k, v, out, true);
+    p.batch = batch; p.seqlen_q = seqlen_q; p.seqlen_k = seqlen_k;
+    p.heads = num_heads; p.kv_heads = kv_num_heads; p.head_dim = head_dim;
+    mfa_forward_params_set_scale(&p);
+    set_windows(p, -1, is_causal ? 0 : -1, seqlen_k);
+    set_extras(p, window_left, window_right, bottom_right);
+    std::optional<at::Tensor> lse;
+    if (return_lse) {
+        lse = at::empty({batch, num_heads, seqlen_q}, q.options().dtype(at::kFloat));
+        p.softmax_lse_ptr = lse->data_ptr<float>();
+    }
+    check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
+    return {out, lse};
+}
+
+OutLse varlen_forward_ex(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v, const at::Tensor& cu_seqlens_q,
+                         const at::Tensor& cu_seqlens_k, int max_seqlen_q, int max_seqlen_k, bool is_causal,
+                         int window_left, int window_right, bool bottom_right, bool return_lse,
+                         const std::optional<at::Tensor>& block_table_) {
+    check_dtypes(q, k, v);
+    c10::DeviceGuard guard(q.device());
+    MFA_CHECK_DEVICE(cu_seqlens_q);
+    MFA_CHECK_DEVICE(cu_seqlens_k);
+    TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_k.scalar_type() == at::kInt,
+                "cu_seqlens_q and cu_seqlens_k must be int32");
+    TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens must be contiguous");
+    TORCH_CHECK(cu_seqlens_q.numel() == cu_seqlens_k.numel() && cu_seqlens_q.numel() >= 1,
+                "cu_seqlens_q and cu_seqlens_k must have batch + 1 elements");
+    TORCH_CHECK(q.dim() == 3, "q must be (total_q, heads, head_dim)");
+    const int total_q = q.size(0), num_heads = q.size(1), head_dim = q.size(2);
+    const int batch = cu_seqlens_q.numel() - 1, kv_num_heads = k.size(-2);
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    at::Tensor out = at::empty_like(q);
+    mfa_forward_params p{};
+    set_tensor_strides(p, q, k, v, out, false);
+    p.batch = batch; p.seqlen_q = max_seqlen_q; p.seqlen_k = max_seqlen_k;
+    p.heads = num_heads; p.kv_heads = kv_num_heads; p.head_dim = head_dim;
+    p.cu_seqlens_q = cu_seqlens_q.data_ptr<int>();
+    p.cu_seqlens_k = cu_seqlens_k.data_ptr<int>();
+    p.total_q = total_q;
+    mfa_forward_params_set_scale(&p);
+    set_windows(p, -1, is_causal ? 0 : -1, max_seqlen_k);
+    set_extras(p, window_left, window_right, bottom_right);
+    if (block_table_.has_value()) {
+        TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "paged k, v must be (num_blocks, page_block_size, heads_k, head_dim)");
+        MFA_CHECK_SHAPE(k, k.size(0), k.size(1), kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v, k.size(0), k.size(1), kv_num_heads, head_dim);
+        set_paged(p, block_table_.value(), k, v, batch);
+    } else {
+        TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "k, v must be (total_k, heads_k, head_dim)");
+        MFA_CHECK_SHAPE(k, k.size(0), kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v, k.size(0), kv_num_heads, head_dim);
+    }
+    std::optional<at::Tensor> lse;
+    if (return_lse) {
+        lse = at::empty({num_heads, total_q}, q.options().dtype(at::kFloat));
+        p.softmax_lse_ptr = lse->data_ptr<float>();
+    }
+    check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
+    return {out, lse};
+}
+
+OutLse kvcache_ex(const at::Tensor& q, const at::Tensor& k_cache, const at::Tensor& v_cache,
+                  const std::optional<at::Tensor>& k_new_, const std::optional<at::Tensor>& v_new_,
+                  const std::optional<at::Tensor>& seqlens_k_, const std::optional<at::Tensor>& block_table_, bool causal,
+                  int window_left, int window_right, int num_splits, bool return_lse) {
+    check_dtypes(q, k_cache, v_cache);
+    c10::DeviceGuard guard(q.device());
+    TORCH_CHECK(q.dim() == 4 && k_cache.dim() == 4 && v_cache.dim() == 4, "q, k_cache, v_cache must be 4-D");
+    const int batch = q.size(0), seqlen_q = q.size(1), num_heads = q.size(2), head_dim = q.size(3);
+    const bool paged_kv = block_table_.has_value();
+    const int kv_num_heads = k_cache.size(-2);
+    TORCH_CHECK(seqlen_q >= 1, "seqlen_q must be at least 1");
+    TORCH_CHECK(head_dim <= 256, "head dimension must be less than or equal to 256");
+    TORCH_CHECK(kv_num_heads > 0 && num_heads % kv_num_heads == 0,
+                "number of key/value heads must be divisible by number of query heads");
+    MFA_CHECK_SHAPE(q, batch, seqlen_q, num_heads, head_dim);
+    mfa_forward_params p{};
+    int seqlen_k;
+    if (paged_kv) {
+        const auto& block_table = block_table_.value();
+        TORCH_CHECK(block_table.dim() == 2, "block_table must be (batch, max_blocks_per_seq)");
+        seqlen_k = block_table.size(1) * k_cache.size(1);
+        MFA_CHECK_SHAPE(k_cache, k_cache.size(0), k_cache.size(1), kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v_cache, k_cache.size(0), k_cache.size(1), kv_num_heads, head_dim);
+        set_paged(p, block_table, k_cache, v_cache, batch);
+    } else {
+        seqlen_k = k_cache.size(1);
+        MFA_CHECK_SHAPE(k_cache, batch, seqlen_k, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(v_cache, batch, seqlen_k, kv_num_heads, head_dim);
+    }
+    const int32_t* seqlens_ptr = nullptr;
+    if (seqlens_k_.has_value()) {
+        const auto& seqlens_k = seqlens_k_.value();
+        MFA_CHECK_DEVICE(seqlens_k);
+        TORCH_CHECK(seqlens_k.scalar_type() == at::kInt && seqlens_k.numel() == batch && seqlens_k.is_contiguous(),
+                    "seqlens_k must be a contiguous int32 tensor with one element per batch entry");
+        seqlens_ptr = seqlens_k.data_ptr<int>();
+    }
+    // ---- append the new tokens first (flash-attn semantics: the cache is updated in place) ----
+    int appended = 0;
+    if (k_new_.has_value() || v_new_.has_value()) {
+        TORCH_CHECK(k_new_.has_value() && v_new_.has_value(), "k and v must be given together");
+        TORCH_CHECK(seqlens_ptr != nullptr, "cache_seqlens is required when appending k, v");
+        const auto &kn = k_new_.value(), &vn = v_new_.value();
+        TORCH_CHECK(kn.scalar_type() == q.scalar_type() && vn.scalar_type() == q.scalar_type(), "k, v dtype must match q");
+        MFA_CHECK_DEVICE(kn);
+        MFA_CHECK_DEVICE(vn);
+        TORCH_CHECK(kn.dim() == 4 && kn.stride(-1) == 1 && vn.stride(-1) == 1, "k, v must be (batch, seqlen_new, heads_k, head_dim)");
+        appended = kn.size(1);
+        MFA_CHECK_SHAPE(kn, batch, appended, kv_num_heads, head_dim);
+        MFA_CHECK_SHAPE(vn, batch, appended, kv_num_heads, head_dim);
+        mfa_kvcache_append_params ap{};
+        ap.k_new = kn.data_ptr(); ap.v_new = vn.data_ptr();
+        ap.k_cache = k_cache.data_ptr(); ap.v_cache = v_cache.data_ptr();
+        ap.kn_batch_stride = kn.stride(0); ap.kn_row_stride = kn.stride(1); ap.kn_head_stride = kn.stride(2);
+        ap.vn_batch_stride = vn.stride(0); ap.vn_row_stride = vn.stride(1); ap.vn_head_stride = vn.stride(2);
+        ap.kc_batch_stride = k_cache.stride(0); ap.kc_row_stride = k_cache.stride(1); ap.kc_head_stride = k_cache.stride(2);
+        ap.vc_batch_stride = v_cache.stride(0); ap.vc_row_stride = v_cache.stride(1); ap.vc_head_stride = v_cache.stride(2);
+        ap.seqlens_k = seqlens_ptr;
+        ap.batch = batch; ap.seqlen_new = appended; ap.kv_heads = kv_num_heads; ap.head_dim = head_dim;
+        ap.seqlen_k = seqlen_k;
+        if (paged_kv) {
+            ap.block_table = p.block_table; ap.block_table_batch_stride = p.block_table_batch_stride;
+            ap.page_block_size = p.page_block_size; ap.max_blocks_per_seq = p.max_blocks_per_seq;
+        }
+        ap.is_bf16 = q.scalar_type() == at::kBFloat16;
+        check_rc(mfa_kvcache_append(&ap, current_stream(q)));
+    }
+    at::Tensor out = at::empty_like(q);
+    set_tensor_strides(p, q, k_cache, v_cache, out, true);
+    p.batch = batch; p.seqlen_q = seqlen_q; p.seqlen_k = seqlen_k;
+    p.heads = num_heads; p.kv_heads = kv_num_heads; p.head_dim = head_dim;
+    mfa_forward_params_set_scale(&p);
+    p.seqlens_k = seqlens_ptr;
+    p.seqlens_k_offset = appended;
+    auto opts = q.options().dtype(at::kFloat);
+    std::optional<at::Tensor> lse;
+    const bool windowed = window_left >= 0 || window_right >= 0;
+    if (seqlen_q == 1 && !windowed) {
+        // single-token decode: causal cannot mask anything (the query is the last position)
+        set_windows(p, -1, -1, seqlen_k);
+        at::Tensor softmax_lse = at::empty({batch, num_heads}, opts);
+        p.softmax_lse_ptr = softmax_lse.data_ptr<float>();
+        p.num_splits = mfa_num_splits_heuristic(num_splits, batch, kv_num_heads, seqlen_k, 0);
+        at::Tensor lse_accum, out_accum;
+        if (p.num_splits > 1) {
+            lse_accum = at::empty({p.num_splits, batch, num_heads}, opts);
+            out_accum = at::empty({p.num_splits, batch, num_heads, head_dim}, opts);
+            p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
+            p.oaccum_ptr = out_accum.data_ptr<float>();
+        }
+        check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
+        if (return_lse) lse = softmax_lse.unsqueeze(-1);
+    } else {
+        // several query tokens against the cache (speculative / chunked decoding): the MFMA path, with the mask
+        // aligned to the last key (query i is position seqlens_k[b] + appended - seqlen_q + i)
+        set_windows(p, -1, causal ? 0 : -1, seqlen_k);
+        set_extras(p, window_left, window_right, true);
+        if (return_lse) {
+            lse = at::empty({batch, num_heads, seqlen_q}, opts);
+            p.softmax_lse_ptr = lse->data_ptr<float>();
+        }
+        check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
+    }
+    return {out, lse};
+}
+
 } // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -267,4 +480,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
     m.def("mini_flash_attention_varlen_forward", &flash_attention_varlen_forward,
           "Forward pass with variable-length sequences");
     m.def("mini_flash_attention_with_kvcache", &mha_fwd_kvcache, "Forward pass with kv-cache for decoding");
+    // opt-in supersets (not in the reference's ABI)
+    m.def("forward_ex", &forward_ex, "Forward pass with sliding window / mask alignment / LSE output");
+    m.def("varlen_forward_ex", &varlen_forward_ex, "Variable-length forward pass with sliding window / LSE output");
+    m.def("kvcache_ex", &kvcache_ex, "KV-cache attention with append, seqlen_q >= 1, sliding window, LSE output");
 }

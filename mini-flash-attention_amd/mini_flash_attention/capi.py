@@ -40,7 +40,24 @@ class ForwardParams(ctypes.Structure):
         ("seqlens_k", _vp),
         ("num_splits", _i32),
         ("softmax_lse_ptr", _vp), ("softmax_lseaccum_ptr", _vp), ("oaccum_ptr", _vp),
-        ("max_blocks_per_seq", _i32), ("num_cus", _i32), ("reserved", _i32),
+        ("max_blocks_per_seq", _i32), ("num_cus", _i32), ("mask_bottom_right", _i32),
+        ("use_local_window", _i32), ("local_window_left", _i32), ("local_window_right", _i32),
+        ("total_q", _i64), ("seqlens_k_offset", _i32), ("reserved", _i32),
+    ]
+
+
+class KvAppendParams(ctypes.Structure):
+    """struct mfa_kvcache_append_params (include/mfa.h)."""
+
+    _fields_ = [
+        ("k_new", _vp), ("v_new", _vp), ("k_cache", _vp), ("v_cache", _vp),
+        ("kn_batch_stride", _i64), ("kn_row_stride", _i64), ("kn_head_stride", _i64),
+        ("vn_batch_stride", _i64), ("vn_row_stride", _i64), ("vn_head_stride", _i64),
+        ("kc_batch_stride", _i64), ("kc_row_stride", _i64), ("kc_head_stride", _i64),
+        ("vc_batch_stride", _i64), ("vc_row_stride", _i64), ("vc_head_stride", _i64),
+        ("seqlens_k", _vp), ("block_table", _vp), ("block_table_batch_stride", _i64),
+        ("batch", _i32), ("seqlen_new", _i32), ("kv_heads", _i32), ("head_dim", _i32),
+        ("seqlen_k", _i32), ("page_block_size", _i32), ("max_blocks_per_seq", _i32), ("is_bf16", _i32),
     ]
 
 
@@ -66,6 +83,9 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.mfa_run_flash_attention_forward.restype = ctypes.c_int
     lib.mfa_run_flash_attention_with_kv_cache.argtypes = [P, _vp]
     lib.mfa_run_flash_attention_with_kv_cache.restype = ctypes.c_int
+    lib.mfa_kvcache_append.argtypes = [ctypes.POINTER(KvAppendParams), _vp]
+    lib.mfa_kvcache_append.restype = ctypes.c_int
+    lib.mfa_kvcache_append_params_sizeof.restype = ctypes.c_size_t
     lib.mfa_num_splits_heuristic.argtypes = [ctypes.c_int] * 5
     lib.mfa_num_splits_heuristic.restype = ctypes.c_int
     lib.mfa_decode_workspace_bytes.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_size_t)] * 2

@@ -21,21 +21,34 @@ except ImportError as e:  # fail loudly: there is no fallback path
     ) from e
 
 
+def _window(window_size):
+    left, right = window_size
+    return int(left), int(right)
+
+
 def flash_attn_func(
     q: torch.Tensor,
     k: torch.Tensor,
     v: torch.Tensor,
     causal: bool = False,
-) -> torch.Tensor:
+    window_size=(-1, -1),
+    return_softmax_lse: bool = False,
+):
     """Dense attention forward, O = softmax(Q K^T / sqrt(D) + mask) V.
 
     q: (batch, seqlen_q, nheads, headdim); k, v: (batch, seqlen_k, nheads_k, headdim), fp16 or bf16 on
     the GPU, nheads % nheads_k == 0 (MQA/GQA: query head h uses KV head h // (nheads // nheads_k)).
     causal: top-left aligned mask (key index > query index is masked), as the reference kernel and
     torch SDPA ``is_causal=True``.
-    Returns (batch, seqlen_q, nheads, headdim) in q's dtype.
+    window_size (superset): (left, right) sliding window, query i sees keys [i - left, i + right]; -1 = unbounded.
+    return_softmax_lse (superset): also return the natural-log LSE, (batch, nheads, seqlen_q) fp32.
+    Returns (batch, seqlen_q, nheads, headdim) in q's dtype (and the LSE when asked).
     """
-    return _C.mini_flash_attention_forward(q, k, v, None, causal, -1, -1)
+    if window_size == (-1, -1) and not return_softmax_lse:
+        return _C.mini_flash_attention_forward(q, k, v, None, causal, -1, -1)
+    left, right = _window(window_size)
+    out, lse = _C.forward_ex(q, k, v, None, causal, left, right, False, return_softmax_lse)
+    return (out, lse) if return_softmax_lse else out
 
 
 def flash_attn_varlen_func(
@@ -48,17 +61,25 @@ def flash_attn_varlen_func(
     max_seqlen_k: int,
     causal: bool = False,
     block_table=None,
-) -> torch.Tensor:
+    window_size=(-1, -1),
+    return_softmax_lse: bool = False,
+):
     """Packed variable-length attention forward (continuous batching).
 
     q: (total_q, nheads, headdim); k, v: (total_k, nheads_k, headdim), or with ``block_table``
     (batch, max_blocks) int32: paged (num_blocks, page_block_size, nheads_k, headdim).
     cu_seqlens_q / cu_seqlens_k: (batch + 1,) int32 cumulative lengths.
+    window_size / return_softmax_lse: supersets, as in flash_attn_func (LSE layout (nheads, total_q)).
     Returns (total_q, nheads, headdim).
     """
-    return _C.mini_flash_attention_varlen_forward(
-        q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, -1, -1, block_table
-    )
+    if window_size == (-1, -1) and not return_softmax_lse:
+        return _C.mini_flash_attention_varlen_forward(
+            q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal, -1, -1, block_table
+        )
+    left, right = _window(window_size)
+    out, lse = _C.varlen_forward_ex(q, k, v, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k, causal,
+                                    left, right, False, return_softmax_lse, block_table)
+    return (out, lse) if return_softmax_lse else out
 
 
 def flash_attn_with_kvcache(
@@ -69,15 +90,29 @@ def flash_attn_with_kvcache(
     block_table: Optional[torch.Tensor] = None,
     num_splits=0,
     causal: bool = False,
-) -> torch.Tensor:
-    """Single-token decode against a KV cache (flash-decoding: split-KV + LSE combine).
+    k: Optional[torch.Tensor] = None,
+    v: Optional[torch.Tensor] = None,
+    window_size=(-1, -1),
+    return_softmax_lse: bool = False,
+):
+    """Attention against a KV cache (flash-decoding: split-KV + LSE combine for single-token steps).
 
-    q: (batch, 1, nheads, headdim); k_cache, v_cache: (batch, seqlen_k, nheads_k, headdim), or with
+    q: (batch, seqlen_q, nheads, headdim); k_cache, v_cache: (batch, seqlen_k, nheads_k, headdim), or with
     ``block_table`` (batch, max_blocks) int32: (num_blocks, page_block_size, nheads_k, headdim).
     cache_seqlens: (batch,) int32 valid lengths; None = whole cache; int = same length for every row.
     num_splits: 0 = choose automatically, 1 = no split, n = split the keys n ways.
+    Supersets of the reference (which supports seqlen_q == 1 without append only):
+      k, v: (batch, seqlen_new, nheads_k, headdim) new tokens, written into the cache at cache_seqlens (in place)
+            before attending over cache_seqlens + seqlen_new keys (cache_seqlens itself is not modified);
+      seqlen_q > 1: the queries are the LAST seqlen_q positions; ``causal`` then masks bottom-right aligned;
+      window_size, return_softmax_lse as in flash_attn_func.
     """
-    assert q.size(1) == 1, "flash_attn_with_kvcache currently only supports seqlen_q=1 for decoding"
     if isinstance(cache_seqlens, int):
         cache_seqlens = torch.full((q.size(0),), cache_seqlens, dtype=torch.int32, device=q.device)
-    return _C.mini_flash_attention_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, False, num_splits)
+    extras = k is not None or v is not None or window_size != (-1, -1) or return_softmax_lse or q.size(1) != 1
+    if not extras:
+        return _C.mini_flash_attention_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, False, num_splits)
+    left, right = _window(window_size)
+    out, lse = _C.kvcache_ex(q, k_cache, v_cache, k, v, cache_seqlens, block_table, causal, left, right, num_splits,
+                             return_softmax_lse)
+    return (out, lse) if return_softmax_lse else out

@@ -32,12 +32,13 @@ def test_library_exports_every_declared_symbol(capi):
     assert {"mfa_run_flash_attention_forward", "mfa_run_flash_attention_with_kv_cache", "mfa_num_splits_heuristic"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"libmfa_hip.so does not export {n}"
-    assert lib.mfa_abi_version() == 1
+    assert lib.mfa_abi_version() == 2
     assert b"gfx950" in lib.mfa_version()
 
 
 def test_struct_layout_matches_ctypes_mirror(capi):
     assert capi.load().mfa_forward_params_sizeof() == ctypes.sizeof(capi.ForwardParams)
+    assert capi.load().mfa_kvcache_append_params_sizeof() == ctypes.sizeof(capi.KvAppendParams)
 
 
 def test_only_one_hip_runtime_is_mapped(capi):
@@ -127,7 +128,9 @@ def test_python_api_rejects_what_the_reference_rejects(mfa):
         mfa.flash_attn_func(q.float(), q.float(), q.float())
     with pytest.raises(RuntimeError, match="same dtype"):
         mfa.flash_attn_func(q, q.bfloat16(), q)
-    with pytest.raises(AssertionError, match="seqlen_q=1"):
+    # seqlen_q > 1 on the kv-cache call is a superset here (the reference asserts seqlen_q == 1, interface.py:116);
+    # CPU tensors are still rejected
+    with pytest.raises(RuntimeError, match="must be on CUDA"):
         mfa.flash_attn_with_kvcache(q, q, q)
     assert mfa.__version__ == "0.1.0"
     assert set(mfa.__all__) == {"flash_attn_func", "flash_attn_varlen_func", "flash_attn_with_kvcache"}
@@ -136,7 +139,8 @@ def test_python_api_rejects_what_the_reference_rejects(mfa):
 def test_extension_abi_is_positional_like_the_reference(mfa):
     """reference csrc/api.cpp:6-8 defines the three functions without py::arg names."""
     import mini_flash_attention._C as C
-    for name in ("mini_flash_attention_forward", "mini_flash_attention_varlen_forward", "mini_flash_attention_with_kvcache"):
+    for name in ("mini_flash_attention_forward", "mini_flash_attention_varlen_forward", "mini_flash_attention_with_kvcache",
+                 "forward_ex", "varlen_forward_ex", "kvcache_ex"):  # the last three are opt-in supersets
         assert hasattr(C, name)
     q = torch.zeros(1, 4, 2, 32, dtype=torch.float16)
     with pytest.raises(TypeError):
