@@ -56,3 +56,24 @@ for (Hq, Hkk) in ((8, 1), (32, 8), (64, 8)):
     byy = 2.0 * (2 * 24 * 8192 * Hkk * 128 + 2 * 24 * Hq * 128)
     med, mn = measure(lambda: mfa.flash_attn_with_kvcache(qq, kk, vv, cache_seqlens=ll), iters=20)
     print(f"decode bf16 B24 Skv8192 {Hq}/{Hkk} D128: med {med*1e3:.1f} us {byy/med/1e6:.0f} GB/s", flush=True)
+
+# ---- §8(f) rows: sliding window, kv-cache append, multi-query kv-cache attention -----------------------------
+B, S, H, D = 16, 8192, 24, 128
+q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float16) for _ in range(3))
+for W in (256, 1024, 4096):
+    med, mn = measure(lambda: mfa.flash_attn_func(q, k, v, causal=True, window_size=(W, 0)), iters=10)
+    pairs = sum(min(r, W) + 1 for r in range(S))
+    fl = 4.0 * B * H * pairs * D
+    print(f"sliding window causal fp16 B{B} S{S} H{H} D{D} left={W}: {med:7.3f} ms  {fl/med/1e9:6.1f} TFLOP/s (visible pairs only)", flush=True)
+med, mn = measure(lambda: mfa.flash_attn_func(q, k, v, causal=True), iters=5)
+print(f"   full causal same shape: {med:7.3f} ms  {4.0*B*H*S*S*D*0.5/med/1e9:6.1f} TFLOP/s", flush=True)
+del q, k, v
+B, Sk, Hq, Hk, D, Sn = 24, 8192, 24, 8, 128, 8
+kc, vc = (torch.randn(B, Sk, Hk, D, device=dev, dtype=torch.bfloat16) for _ in range(2))
+lens = torch.full((B,), Sk - 64, device=dev, dtype=torch.int32)
+for Sn in (1, 8, 64):
+    qn = torch.randn(B, Sn, Hq, D, device=dev, dtype=torch.bfloat16)
+    kn, vn = (torch.randn(B, Sn, Hk, D, device=dev, dtype=torch.bfloat16) for _ in range(2))
+    med, mn = measure(lambda: mfa.flash_attn_with_kvcache(qn, kc, vc, cache_seqlens=lens, causal=True, k=kn, v=vn), iters=20)
+    by = 2.0 * (2 * B * (Sk - 64 + Sn) * Hk * D)
+    print(f"kv-cache append+attend bf16 B{B} Skv{Sk-64}+{Sn} {Hq}/{Hk} D{D} Sq={Sn}: {med*1e3:7.1f} us  {by/med/1e6:6.0f} GB/s of K+V", flush=True)
