@@ -118,11 +118,14 @@ int mfa_device_cu_count(int device) {
 
 // The reference sizes its split count from batch*QUERY heads on 2*SMs (api.cpp:269-302).  The native kernel runs
 // one workgroup per (batch, KV head, split) and every wave keeps 16 KiB of loads in flight, so it saturates HBM
-// with well under one workgroup per CU: measured on MI355X (tools/split_sweep.py) the best total is ~0.5-1
-// workgroup per CU, and splitting beyond that only adds combine work.  Rule: no split once batch*kv_heads reaches
-// 3/4 of the CUs; otherwise enough splits to reach that many workgroups, never below 4 tiles of 64 keys per
-// split, evened out.  Only the ARGUMENT semantics are the reference's: <1 = auto, explicit values are clamped to
-// the number of 64-key tiles (api.cpp:320-327).
+// with well under one workgroup per CU.  Measured on MI355X (tools/split_sweep.py, profiles/r01c_sweep.txt) the time
+// follows workgroup QUANTISATION over the CUs, not occupancy: W = B*Hkv*splits workgroups run at
+//   eff(W) = min(1, W / (3/4 CUs))         for W <= CUs   (192 workgroups on 256 CUs already reach 6.1 TB/s)
+//          = (W / CUs) / ceil(W / CUs)      for W  > CUs   (384 = 1.5/CU is 10 % slower than 192 or 768)
+// and splitting costs the combine launch (~4 us) plus ~0.15 us per split of partials.  With the streaming time
+// estimated as K+V bytes / 6 TB/s (head_dim 128 assumed) the count minimising  t_stream / eff + t_combine  is
+// taken, never below 4 tiles of 64 keys per split, evened out.  Only the ARGUMENT semantics are the reference's:
+// <1 = auto, explicit values are clamped to the number of 64-key tiles (api.cpp:320-327) and to 128.
 int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_k, int num_cus) {
     const int ntiles = (seqlen_k + 63) / 64;
     if (ntiles <= 1) return 1;
@@ -134,18 +137,26 @@ int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_
         num_cus = mfa_device_cu_count(-1);
         if (num_cus <= 0) num_cus = 256;
     }
-    const long base = static_cast<long>(batch) * kv_heads;
+    const double base = static_cast<double>(batch) * kv_heads;
     if (base <= 0) return 1;
-    const long target = (3L * num_cus + 3) / 4;
-    if (base >= target) return 1;
-    long splits = (target + base - 1) / base;
-    const long max_splits = ntiles / 4 > 1 ? ntiles / 4 : 1;
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 128) splits = 128;
-    if (splits <= 1) return 1;
-    const long per = (ntiles + splits - 1) / splits;
-    splits = (ntiles + per - 1) / per;
-    return static_cast<int>(splits);
+    int max_splits = ntiles / 4 > 1 ? ntiles / 4 : 1;
+    if (max_splits > 128) max_splits = 128;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= max_splits; ++s) {
+        const int per = (ntiles + s - 1) / s;
+        if ((ntiles + per - 1) / per != s) continue; // not an even split: the evened count is evaluated on its own
+        const double w = base * s;
+        const double eff = w <= num_cus ? (w / (0.75 * num_cus) < 1.0 ? w / (0.75 * num_cus) : 1.0)
+                                        : (w / num_cus) / std::ceil(w / num_cus);
+        const double t_stream_us = base * seqlen_k * 512.0 / 6.0e6;
+        const double cost = t_stream_us / eff + (s > 1 ? 4.0 + 0.15 * s : 0.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
 }
 
 void mfa_decode_workspace_bytes(int num_splits, int batch, int heads, int head_dim, size_t* oaccum_bytes,
