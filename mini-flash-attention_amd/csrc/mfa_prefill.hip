@@ -208,6 +208,18 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const uint32_t k_sb = (uint32_t)(2 * a.k_row_stride), v_sb = (uint32_t)(2 * a.v_row_stride); // row pitch, bytes
     const uint32_t k_go = srow * k_sb + 16 * s_kch, v_go = srow * v_sb + 16 * s_vch;
     const uint32_t k_gmax = last_key * k_sb + 16 * s_kch, v_gmax = last_key * v_sb + 16 * s_vch;
+    // paged K/V: page id of each of this lane's NI rows of the NEXT tile to be fetched
+    int pid_n[NI];
+    auto load_pids = [&](int j) {
+        if constexpr (PAGED) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int key = min(j * kBN + i * RPI * NW + srow, last_key);
+                const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
+                pid_n[i] = table[min(pg, a.max_blocks - 1)];
+            }
+        }
+    };
     // piece pc of tile j: pieces 0..NI-1 are K rows, NI..2*NI-1 are V rows
     auto stage_piece = [&](int j, auto bufc, int pc) {
         constexpr int BUF = decltype(bufc)::value;
@@ -218,10 +230,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         const uint32_t dst = __builtin_amdgcn_readfirstlane(
             lds_address((is_v ? sV : sK) + BUF * TILE_BYTES + (row + wave * RPI) * RB));
         if constexpr (PAGED) {
+            // page ids were looked up one tile earlier (pid_n): a block-table load right here would be waited for by
+            // the compiler with a vmcnt that also drains every DMA piece issued before it
             const int key = min(j * kBN + row + srow, last_key);
             const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
             const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
-            const int64_t pid = table[min(pg, a.max_blocks - 1)];
+            const int64_t pid = pid_n[is_v ? pc - NI : pc];
             if (is_v) lds_dma16(vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch, dst);
             else lds_dma16(kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row), dst);
         } else {
@@ -272,7 +286,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const float c = a.scale_log2;
     const int wrow0 = m0 + 32 * wave; // first query row of this wave
 
+    load_pids(j_lo);
     if (nt > 0 && sk > 0) stage_dma(j_lo, std::integral_constant<int, 0>{});
+    load_pids(j_lo + 1);
     // Everything issued so far (Q fragments, tile 0's DMA) is waited for HERE: with the Q loads still on the
     // scoreboard at the loop header, hipcc re-waits for them inside the loop (vmcnt(7..0) before the QK^T
     // MFMAs), which from the second iteration on would drain the just-issued DMA of the next tile.
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         // a wave none of whose rows can see this tile (above the causal diagonal / outside the window) skips it
         const bool active = (!has_hi || j * kBN <= wrow0 + 31 + hi) && (!has_lo || j * kBN + kBN - 1 >= wrow0 + lo);
         if (!active && dma) stage_dma(j + 1, nbuf);
+        if (!active) load_pids(j + 2);
         if (active) {
             constexpr int kt = BUF * TILE_BYTES; // byte offset of this tile's K (and, past sK, V) buffer
             constexpr int vt = BUF * TILE_BYTES;
@@ -319,6 +336,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 }
                 s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
             }
+            load_pids(j + 2); // (paged) consumed by the next tile's DMA, after this tile's end-of-tile wait
             // mask: key > row + hi (causal: hi = 0, top-left) or key >= sk; register i of block kb is key
             // j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
             const bool need_mask = (has_hi && j * kBN + kBN - 1 > wrow0 + hi) || (j + 1) * kBN > sk;
