@@ -417,6 +417,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         if (!(ABL & 2)) __syncthreads();
     };
 
+    if (ABL & 256) nt = 0; // timing-only: prologue + epilogue, no tiles
     for (int j = 0; j < nt; j += 2) {
         tile(j, std::integral_constant<int, 0>{});
         if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
@@ -495,6 +496,7 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
         case 32: kern = prefill_fwd_kernel<T, D, NW, PAGED, 32>; break;
         case 64: kern = prefill_fwd_kernel<T, D, NW, PAGED, 64>; break;
         case 66: kern = prefill_fwd_kernel<T, D, NW, PAGED, 66>; break;
+        case 256: kern = prefill_fwd_kernel<T, D, NW, PAGED, 256>; break;
         default: break;
         }
     }
