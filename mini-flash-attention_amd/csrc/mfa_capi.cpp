@@ -52,8 +52,8 @@ int check_common(const mfa_forward_params* p) {
     // non-paged K/V rows are addressed with 32-bit byte offsets from a per-(batch, kv head) base
     if (!p->block_table) {
         const int64_t span_k = (int64_t)p->seqlen_k * p->k_row_stride * 2, span_v = (int64_t)p->seqlen_k * p->v_row_stride * 2;
-        const bool varlen = p->cu_seqlens_k != nullptr; // (varlen: seqlen_k is the longest sequence)
-        if (!varlen && (span_k >= (1LL << 32) || span_v >= (1LL << 32)))
+        // (varlen: seqlen_k is the longest sequence; offsets are relative to each sequence's first row)
+        if (span_k >= (1LL << 32) || span_v >= (1LL << 32))
             return fail(MFA_ERR_UNSUPPORTED, "one batch element of K/V spans 4 GiB or more; use a paged cache");
     }
     if (p->block_table) {

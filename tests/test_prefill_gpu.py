@@ -199,3 +199,19 @@ def test_baseline_config2_full_size(mfa, capi):
     # non-causal at the same size, one batch element spot-checked
     outn = hp.prefill("api", mfa, capi, q, k, v, False)
     assert_close(outn[5:6], hp.sdpa_gpu(q[5:6], k[5:6], v[5:6], False), p_rounded=True, what="config2 non-causal")
+
+
+def test_long_sequences(mfa, capi):
+    """S = 16384 and 32768: index arithmetic far past the sizes the reference tests (max 8192, tests/test_gqa.py:334)."""
+    for S, causal in ((16384, True), (32768, True), (20000, False)):
+        q, k, v = rnd(1, S, 2, 128, dtype=torch.bfloat16, seed=1), rnd(1, S, 1, 128, dtype=torch.bfloat16, seed=2), rnd(1, S, 1, 128, dtype=torch.bfloat16, seed=3)
+        out = hp.prefill("api", mfa, capi, q, k, v, causal)
+        # reference on a sample of rows (a full fp32 score matrix would be 8.6 GB at S = 32768)
+        rows = torch.tensor([0, 1, 63, 64, 4095, S // 2, S - 129, S - 1], device=DEV)
+        qs = q[:, rows].float()
+        s = torch.einsum("bqhd,bkd->bhqk", qs, k[:, :, 0].float()) / 128 ** 0.5
+        if causal:
+            s = s.masked_fill(torch.arange(S, device=DEV)[None, None, None, :] > rows[None, None, :, None], float("-inf"))
+        ref = torch.einsum("bhqk,bkd->bqhd", torch.softmax(s, -1), v[:, :, 0].float())
+        assert_close(out[:, rows], ref, p_rounded=True, what=f"S={S} causal={causal}")
+        assert torch.isfinite(out.float()).all()
