@@ -365,11 +365,14 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 for (int i = 0; i < 16; ++i) mt = fmaxf(mt, s[kb][i]);
             mt = fmaxf(mt, swap32(mt));
             const float m_new = fmaxf(m_run, mt);
-            const float ms = (m_new == -INFINITY) ? 0.f : m_new;
-            const float mc = ms * c;
-            // rescale O and l only when some row of this wave raised its max (alpha == 1 exactly otherwise)
-            if (__builtin_amdgcn_ballot_w64(m_new > m_run) != 0) {
-                const float alpha = fast_exp2((m_run - ms) * c);
+            // Deferred rescale: O and l are rescaled (and the reference max moved) only when some row of this wave
+            // grew its max by more than THR in the exponent; otherwise the old max stays and P may reach 2^THR
+            // instead of 1 -- the same relative precision in fp16/bf16 and in the fp32 sums, one O-wide multiply
+            // pass less per tile.  THR = 0 is the textbook update (every growth rescales).
+            constexpr float THR = (ABL & 512) ? 0.f : 6.f;
+            if (__builtin_amdgcn_ballot_w64((m_new - m_run) * c > THR) != 0) {
+                const float msn = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = fast_exp2((m_run - msn) * c);
                 l_run *= alpha;
 #pragma unroll
                 for (int d = 0; d < DB; ++d)
@@ -377,6 +380,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     for (int i = 0; i < 16; ++i) oacc[d][i] *= alpha;
                 m_run = m_new;
             }
+            const float ms = (m_run == -INFINITY) ? 0.f : m_run;
+            const float mc = ms * c;
             // p = exp2(s*c - m*c): packed fma / packed add on register pairs, one v_exp per element
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 c2 = {c, c}, nmc2 = {-mc, -mc};
@@ -497,6 +502,7 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
         case 64: kern = prefill_fwd_kernel<T, D, NW, PAGED, 64>; break;
         case 66: kern = prefill_fwd_kernel<T, D, NW, PAGED, 66>; break;
         case 256: kern = prefill_fwd_kernel<T, D, NW, PAGED, 256>; break;
+        case 512: kern = prefill_fwd_kernel<T, D, NW, PAGED, 512>; break;
         default: break;
         }
     }

@@ -215,3 +215,22 @@ def test_long_sequences(mfa, capi):
         ref = torch.einsum("bhqk,bkd->bqhd", torch.softmax(s, -1), v[:, :, 0].float())
         assert_close(out[:, rows], ref, p_rounded=True, what=f"S={S} causal={causal}")
         assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("per_tile_growth", [1.0, 4.0, 5.9, 6.1, 13.0])
+def test_deferred_rescale_slowly_growing_max(mfa, capi, dtype, per_tile_growth):
+    """The kernel moves its reference max only when a row's max grew by more than THR = 6 (log2 units) since the last
+    move, so P can reach 2^6 in between.  Scores that ramp by a fixed amount per 64-key tile sit just below / above
+    the threshold for many consecutive tiles (guide rule 26: the rare branch needs an input that forces it)."""
+    S, D = 640, 128
+    c = (D ** -0.5) * 1.4426950408889634
+    slope = per_tile_growth / (64 * c)            # raw-score growth per key
+    q = rnd(1, 96, 2, D, dtype=dtype, seed=1) * 0.05
+    k = rnd(1, S, 2, D, dtype=dtype, seed=2) * 0.05
+    v = rnd(1, S, 2, D, dtype=dtype, seed=3)
+    q[..., 0] = 4.0
+    k[..., 0] = (torch.arange(S, device=DEV, dtype=torch.float32) * slope / 4.0).to(dtype)[None, :, None]
+    for causal in (False, True):
+        out = hp.prefill("capi", mfa, capi, q, k, v, causal)
+        assert_close(out, hp.sdpa_gpu(q, k, v, causal), p_rounded=True, what=f"growth={per_tile_growth} causal={causal}")
