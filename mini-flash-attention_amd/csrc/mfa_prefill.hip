@@ -190,6 +190,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // position p FETCHES the global chunk that belongs there (swizzle on the source address; the destination
     // cannot scatter).  Rows past the key length are clamped to the last valid row: their scores are masked to
     // -inf, so P is exactly 0 there and the duplicated (finite) V rows contribute nothing.
+    const uint32_t smem_lds = lds_address(smem);
     constexpr int LPR_ = RB / 16;            // lanes (16-byte positions) per LDS row
     constexpr int RPI = 64 / LPR_;           // rows per wave-instruction
     constexpr int NI = kBN / (RPI * NW) > 0 ? kBN / (RPI * NW) : 1; // instructions per wave per tile (K, and V)
@@ -226,9 +227,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         if (NI * RPI * NW > kBN && srow >= kBN) return; // (tiny head dims: fewer rows than lanes cover)
         const bool is_v = pc >= NI;
         const int row = (is_v ? pc - NI : pc) * RPI * NW; // + srow; wave-uniform part
-        // wave-uniform LDS piece base (readfirstlane makes the uniformity provable for the "s" operand)
+        // wave-uniform LDS piece base, as an integer off the one address conversion done at kernel entry (a
+        // generic->LDS pointer cast per piece costs a null check: s_cmp_lg_u64 + s_cselect); readfirstlane makes
+        // the uniformity provable for the "s" operand
         const uint32_t dst = __builtin_amdgcn_readfirstlane(
-            lds_address((is_v ? sV : sK) + BUF * TILE_BYTES + (row + wave * RPI) * RB));
+            smem_lds + (is_v ? 2 * TILE_BYTES : 0) + BUF * TILE_BYTES + (row + wave * RPI) * RB);
         if constexpr (PAGED) {
             // page ids were looked up one tile earlier (pid_n): a block-table load right here would be waited for by
             // the compiler with a vmcnt that also drains every DMA piece issued before it
@@ -323,19 +326,26 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             for (int ks = 0; ks < PF; ++ks)
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) kf[ks][kb] = *(const frag8*)(k_rd[ks] + kt + kb * 32 * RB);
+            // (two copies of the k-step loop, with and without the DMA pieces: a per-step `if (dma)` would cut the
+            // MFMA / ds_read stream into KS basic blocks)
+            auto qk_steps = [&](auto with_dma) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                if (ks + PF < KS) {
+                for (int ks = 0; ks < KS; ++ks) {
+                    if (ks + PF < KS) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb) kf[ks + PF][kb] = *(const frag8*)(k_rd[ks + PF] + kt + kb * 32 * RB);
+                        for (int kb = 0; kb < 2; ++kb)
+                            kf[ks + PF][kb] = *(const frag8*)(k_rd[ks + PF] + kt + kb * 32 * RB);
+                    }
+                    s[0] = E::mfma32(kf[ks][0], qf[ks], s[0]);
+                    if constexpr (decltype(with_dma)::value) {
+#pragma unroll
+                        for (int pc = ks * 2 * NI / KS; pc < (ks + 1) * 2 * NI / KS; ++pc) stage_piece(j + 1, nbuf, pc);
+                    }
+                    s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
                 }
-                s[0] = E::mfma32(kf[ks][0], qf[ks], s[0]);
-                if (dma) {
-#pragma unroll
-                    for (int pc = ks * 2 * NI / KS; pc < (ks + 1) * 2 * NI / KS; ++pc) stage_piece(j + 1, nbuf, pc);
-                }
-                s[1] = E::mfma32(kf[ks][1], qf[ks], s[1]);
-            }
+            };
+            if (dma) qk_steps(std::true_type{});
+            else qk_steps(std::false_type{});
             load_pids(j + 2); // (paged) consumed by the next tile's DMA, after this tile's end-of-tile wait
             // mask: key > row + hi (causal: hi = 0, top-left) or key >= sk; register i of block kb is key
             // j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
