@@ -106,6 +106,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31;
     const int h = lane >> 5;
+    // (developer builds, ABL & 1024: phase timestamps of every workgroup go to the LSE buffer; tools/wg_timeline.py)
+    long long stamp[4] = {0, 0, 0, 0};
+    if constexpr ((ABL & 1024) != 0) stamp[0] = wall_clock64();
 
     // ---- workgroup -> (batch, head, query block) -------------------------------------------------
     // XCD-aware: blocks bid, bid+8, ... share an XCD (round-robin dispatch), so XCD x = bid & 7 owns a contiguous
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // MFMAs), which from the second iteration on would drain the just-issued DMA of the next tile.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
+    if constexpr ((ABL & 1024) != 0) stamp[1] = wall_clock64();
 
     // one key tile out of LDS buffer BUF (compile-time, so every LDS offset is an immediate)
     auto tile = [&](int jj, auto bufc) {
@@ -438,10 +442,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
     }
 
+    if constexpr ((ABL & 1024) != 0) stamp[2] = wall_clock64();
     // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
     const float l_tot = l_run + swap32(l_run);
     const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-    if (a.lse && h == 0 && qrow < sq) { // natural-log LSE of the scaled scores; -inf for a row that saw no key
+    if (!(ABL & 1024) && a.lse && h == 0 && qrow < sq) { // natural-log LSE of the scaled scores; -inf for a row that saw no key
         const float lse = l_tot > 0.f ? m_run * a.scale + __logf(l_tot) : -INFINITY;
         const int64_t idx = a.cu_q ? (int64_t)hq * a.total_q + a.cu_q[b] + qrow
                                    : ((int64_t)b * a.heads + hq) * a.seqlen_q + qrow;
@@ -480,6 +485,16 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             if (grow < sq) *(u32x4*)(obase + 2 * ((int64_t)grow * a.o_row_stride) + 16 * ch) = val;
         }
     }
+    if constexpr ((ABL & 1024) != 0) {
+        if (a.lse && tid == 0) {
+            long long* dbg = (long long*)a.lse + (size_t)blockIdx.x * 8;
+            dbg[0] = stamp[0]; dbg[1] = stamp[1]; dbg[2] = stamp[2]; dbg[3] = wall_clock64();
+            dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+            dbg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // XCC_ID
+            dbg[6] = nt;
+            dbg[7] = 0x5A5A5A5A5A5A5A5ALL;
+        }
+    }
 }
 
 template <typename T, int D, int NW, bool PAGED>
@@ -513,6 +528,7 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
         case 66: kern = prefill_fwd_kernel<T, D, NW, PAGED, 66>; break;
         case 256: kern = prefill_fwd_kernel<T, D, NW, PAGED, 256>; break;
         case 512: kern = prefill_fwd_kernel<T, D, NW, PAGED, 512>; break;
+        case 1024: kern = prefill_fwd_kernel<T, D, NW, PAGED, 1024>; break;
         default: break;
         }
     }
