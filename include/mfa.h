@@ -146,9 +146,19 @@ void mfa_forward_params_set_scale(mfa_forward_params* p);
 /* Prefill / varlen / paged-prefill forward: O = softmax(scale*Q K^T + mask) V. */
 int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_stream);
 
-/* Decode (seqlen_q == 1) forward with optional split-KV + LSE combine.
- * p->num_splits must already be resolved (>= 1); workspaces must be present when it is > 1. */
+/* Attention of (B, seqlen_q, H, D) queries over a K/V cache with optional split-KV + LSE combine.
+ * seqlen_q == 1 is the reference's flash decoding (run_flash_attention_with_kv_cache, flash.h:77).  seqlen_q > 1
+ * (not in the reference: speculative / chunked decoding) treats the queries as the LAST seqlen_q positions:
+ * is_causal and the local window align to the last valid key (flash-attn >= 2.1), whatever mask_bottom_right says.
+ * seqlens_k (+ seqlens_k_offset), block_table and softmax_lse_ptr ((B,H,seqlen_q)) are honoured.
+ * p->num_splits must already be resolved (>= 1, from mfa_kvcache_plan); workspaces must be present when it is > 1. */
 int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream);
+
+/* What the kv-cache entry wants for this problem (shape fields, num_cus and num_splits of *p are read; num_splits
+ * < 1 = choose): the key-split count to put into p->num_splits and the bytes of the two fp32 workspaces
+ * (oaccum: (S,B,Sq,H,D), lseaccum: (S,B,Sq,H); both 0 when S == 1).  For seqlen_q == 1 and a GQA group <= 4 this
+ * is mfa_num_splits_heuristic + mfa_decode_workspace_bytes. */
+int mfa_kvcache_plan(const mfa_forward_params* p, int* num_splits, size_t* oaccum_bytes, size_t* lse_bytes);
 
 /* Append new K/V rows to the cache (see mfa_kvcache_append_params). */
 int mfa_kvcache_append(const mfa_kvcache_append_params* p, void* hip_stream);

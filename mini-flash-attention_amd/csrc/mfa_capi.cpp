@@ -7,9 +7,11 @@
 // 128-bit accesses, supported head dims, workspaces for split decode).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "mfa_launch.h"
 
@@ -187,18 +189,104 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
     return MFA_OK;
 }
 
+// Which kernel serves a kv-cache call (the dispatch of mfa_run_flash_attention_with_kv_cache and of mfa_kvcache_plan):
+//   kKvDecode  seqlen_q == 1 and a GQA group of at most 4: the vector kernel of mfa_decode.hip (every K/V byte once,
+//              G heads in registers; 73-78 % of HBM peak);
+//   kKvPacked  seqlen_q > 1, or a larger group: the G * seqlen_q query rows of a KV head packed into 32-row MFMA
+//              tiles, keys split over workgroups (MQ instances of the prefill kernel);
+//   kKvPrefill everything else (long query blocks, head dims without a packed instance): the prefill kernel per query
+//              head over the cached keys, causal aligned to the last key.
+enum { kKvDecode = 0, kKvPacked = 1, kKvPrefill = 2 };
+static int kvcache_route(const mfa_forward_params* p) {
+    static const int env = [] { const char* e = getenv("MFA_KVCACHE_PACKED"); return e ? atoi(e) : -1; }();
+    const int g = p->kv_heads > 0 ? p->heads / p->kv_heads : 1;
+    const bool has_packed = p->head_dim == 64 || p->head_dim == 128 || p->head_dim == 256;
+    const int64_t rows = static_cast<int64_t>(p->seqlen_q) * g;
+    bool packed = has_packed && rows <= 512 && (p->seqlen_q > 1 || g > 4 || p->use_local_window);
+    if (env == 0) packed = false;
+    if (env == 1 && has_packed) packed = true;
+    if (packed) return kKvPacked;
+    return p->seqlen_q == 1 && !p->use_local_window ? kKvDecode : kKvPrefill; // (the vector kernel has no window)
+}
+
+// key splits for the packed kernel: W = B*Hkv*row_blocks*splits workgroups run in ceil(W / slots) rounds of
+// (tiles per split + ~3 tiles of fixed cost); splitting adds the combine launch
+static int packed_num_splits(const mfa_forward_params* p, int num_cus) {
+    const int ntiles = (p->seqlen_k + 63) / 64;
+    const int g = p->heads / p->kv_heads;
+    const int64_t items = static_cast<int64_t>(p->batch) * p->kv_heads * ((static_cast<int64_t>(p->seqlen_q) * g + 127) / 128);
+    if (num_cus <= 0) num_cus = mfa_device_cu_count(-1);
+    if (num_cus <= 0) num_cus = 256;
+    const int64_t slots = static_cast<int64_t>(num_cus) * (p->head_dim <= 128 ? 2 : 1);
+    int best = 1;
+    double best_cost = 1e300;
+    const int smax = std::max(1, std::min(128, ntiles / 4));
+    for (int s = 1; s <= smax; ++s) {
+        const double rounds = std::ceil(static_cast<double>(items * s) / slots);
+        const double cost = rounds * ((ntiles + s - 1) / s + 3.0) + (s > 1 ? 3.0 + 0.1 * s : 0.0);
+        if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return best;
+}
+
+int mfa_kvcache_plan(const mfa_forward_params* p, int* num_splits, size_t* oaccum_bytes, size_t* lse_bytes) {
+    if (!p || p->kv_heads <= 0 || p->heads % p->kv_heads != 0 || p->seqlen_q < 1)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "mfa_kvcache_plan: heads / kv_heads / seqlen_q not set");
+    const int ntiles = std::max(1, (p->seqlen_k + 63) / 64);
+    int s = 1;
+    switch (kvcache_route(p)) {
+    case kKvDecode: s = mfa_num_splits_heuristic(p->num_splits, p->batch, p->kv_heads, p->seqlen_k, p->num_cus); break;
+    case kKvPacked: s = p->num_splits >= 1 ? std::min(std::min(p->num_splits, ntiles), 128) : packed_num_splits(p, p->num_cus); break;
+    default: s = 1; break;
+    }
+    if (num_splits) *num_splits = s;
+    size_t o = 0, l = 0;
+    if (s > 1) {
+        l = sizeof(float) * static_cast<size_t>(s) * p->batch * p->seqlen_q * p->heads;
+        o = l * p->head_dim;
+    }
+    if (oaccum_bytes) *oaccum_bytes = o;
+    if (lse_bytes) *lse_bytes = l;
+    return MFA_OK;
+}
+
 int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream) {
     if (int rc = check_common(p)) return rc;
-    if (p->seqlen_q != 1)
-        return fail(MFA_ERR_INVALID_ARGUMENT, "flash decoding expects seqlen_q == 1, got %d", p->seqlen_q);
+    if (p->seqlen_q < 1) return fail(MFA_ERR_INVALID_ARGUMENT, "seqlen_q must be >= 1, got %d", p->seqlen_q);
+    if (p->cu_seqlens_q || p->cu_seqlens_k)
+        return fail(MFA_ERR_INVALID_ARGUMENT, "the kv-cache entry takes (B, Sq, H, D) queries, not packed sequences");
     if (p->num_splits > 128)
-        return fail(MFA_ERR_INVALID_ARGUMENT, "num_splits must be <= 128 (got %d); see mfa_num_splits_heuristic", p->num_splits);
+        return fail(MFA_ERR_INVALID_ARGUMENT, "num_splits must be <= 128 (got %d); see mfa_kvcache_plan", p->num_splits);
     if (p->num_splits > 1 && (!p->softmax_lseaccum_ptr || !p->oaccum_ptr))
         return fail(MFA_ERR_WORKSPACE, "num_splits=%d needs softmax_lseaccum_ptr and oaccum_ptr", p->num_splits);
+    if (p->use_local_window && (p->local_window_left < -1 || p->local_window_right < -1))
+        return fail(MFA_ERR_INVALID_ARGUMENT, "local_window_left/right must be >= -1");
     // O may be strided: the combine kernel honours o_*_stride (the reference assumes contiguous, decode.cuh:730)
     if (p->batch == 0) return MFA_OK;
-    const int rc = mfa::launch_decode(*p, static_cast<hipStream_t>(hip_stream));
-    if (rc) return fail(MFA_ERR_LAUNCH, "decode launch failed: %s", hipGetErrorString(hipGetLastError()));
+    const hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const int route = kvcache_route(p);
+    if (route == kKvDecode) {
+        const int rc = mfa::launch_decode(*p, stream);
+        if (rc) return fail(MFA_ERR_LAUNCH, "decode launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return MFA_OK;
+    }
+    // the queries are the LAST seqlen_q positions of the sequence: causal / windows align to the last key
+    mfa_forward_params q = *p;
+    q.mask_bottom_right = 1;
+    if (p->seqlen_q == 1 && !p->use_local_window) q.is_causal = 0; // one query at the end sees every key
+    if (route == kKvPrefill) {
+        if (p->head_dim % 32 != 0)
+            return fail(MFA_ERR_UNSUPPORTED, "kv-cache attention with seqlen_q > 1 needs head_dim %% 32 == 0 (got %d)", p->head_dim);
+        if (p->num_splits > 1) return fail(MFA_ERR_INVALID_ARGUMENT, "this shape runs unsplit: ask mfa_kvcache_plan for num_splits");
+        const int rc = mfa::launch_prefill(q, stream);
+        if (rc) return fail(MFA_ERR_LAUNCH, "kv-cache prefill launch failed: %s", hipGetErrorString(hipGetLastError()));
+        return MFA_OK;
+    }
+    const int rc = mfa::launch_kvcache_packed(q, stream);
+    if (rc) return fail(MFA_ERR_LAUNCH, "packed kv-cache launch failed: %s", hipGetErrorString(hipGetLastError()));
     return MFA_OK;
 }
 

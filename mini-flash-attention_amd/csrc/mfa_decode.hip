@@ -43,6 +43,10 @@ struct DecodeArgs {
     int32_t num_splits, nchunks;
     int32_t seqlens_k_offset; // added to seqlens_k[b] (rows appended just before this launch)
     float scale_log2; // softmax_scale * log2(e)
+    // combine only: query positions per batch entry (1 for flash decoding; the packed-row kv-cache kernels of
+    // mfa_prefill.hip write (S,B,Sq,H) partials) and the row stride of O
+    int32_t seqlen_q;
+    int64_t o_row_stride;
 };
 
 constexpr int kDecodeThreads = 256;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
 }
 
 // O = sum_s o_s * exp(lse_s - LSE), LSE = ln sum_s exp(lse_s)  (decode.cuh:718-747, max-subtracted).
-// One workgroup per (batch, head): the split weights go through LDS once, then the 256 threads cover
+// One workgroup per (batch, query position, head): the split weights go through LDS once, then the 256 threads cover
 // (split lane, column) so the partial-O reads of different splits are in flight together.
 template <typename T>
 __global__ __launch_bounds__(256) void decode_combine_kernel(const DecodeArgs a) {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) void decode_combine_kernel(const DecodeArgs a)
     __shared__ float red[256];
     __shared__ float stat[2];        // M, W
     const int D = a.head_dim, S = a.num_splits;
-    const int64_t BH = (int64_t)a.batch * a.heads;
+    const int64_t BH = (int64_t)a.batch * a.seqlen_q * a.heads;
     const int64_t bh = blockIdx.x;
     const int tid = threadIdx.x;
     const float lse_t = tid < S ? a.lse_acc[tid * BH + bh] : -INFINITY;
@@ -333,10 +337,14 @@ __global__ __launch_bounds__(256) void decode_combine_kernel(const DecodeArgs a)
     if (tid < D) {
         for (int k = 1; k < SL; ++k) o += red[k * D + tid];
         o = W > 0.f ? o / W : 0.f;
-        const int b = bh / a.heads, h = bh % a.heads;
-        char* op = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)h * a.o_head_stride + tid);
+        const int h = bh % a.heads;
+        const int64_t t = bh / a.heads;
+        const int pos = t % a.seqlen_q;
+        const int64_t b = t / a.seqlen_q;
+        char* op = (char*)a.o + 2 * (b * a.o_batch_stride + pos * a.o_row_stride + (int64_t)h * a.o_head_stride + tid);
         *(uint16_t*)op = (uint16_t)Elem<T>::pack(o, 0.f);
-        if (tid == 0 && a.lse) a.lse[bh] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
+        if (tid == 0 && a.lse) // (B, H, Sq)
+            a.lse[(b * a.heads + h) * a.seqlen_q + pos] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
     }
 }
 
@@ -397,6 +405,8 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
     a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
     a.scale_log2 = p.softmax_scale_log2;
     a.seqlens_k_offset = p.seqlens_k_offset;
+    a.seqlen_q = 1;
+    a.o_row_stride = 0;
     const int G = a.group;
     static const int env_gtmax = [] { const char* e = getenv("MFA_DECODE_GT_MAX"); return e ? atoi(e) : 0; }();
     const int gtmax = env_gtmax > 0 ? env_gtmax : 8;
@@ -410,6 +420,20 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
     }
     a.nchunks = (G + gt - 1) / gt;
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
+}
+
+// LSE-weighted merge of (S, B, Sq, H[, D]) partials into O / LSE, for the packed-row kv-cache kernels
+int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream) {
+    DecodeArgs a{};
+    a.o = p.o_ptr; a.lse = p.softmax_lse_ptr; a.lse_acc = p.softmax_lseaccum_ptr; a.o_acc = p.oaccum_ptr;
+    a.o_batch_stride = p.o_batch_stride; a.o_head_stride = p.o_head_stride; a.o_row_stride = p.o_row_stride;
+    a.batch = p.batch; a.heads = p.heads; a.head_dim = p.head_dim; a.num_splits = p.num_splits;
+    a.seqlen_q = p.seqlen_q;
+    const int64_t rows = (int64_t)p.batch * p.seqlen_q * p.heads;
+    if (rows <= 0) return 0;
+    if (p.is_bf16) hipLaunchKernelGGL((decode_combine_kernel<BFloat>), dim3((unsigned)rows), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((decode_combine_kernel<Half>), dim3((unsigned)rows), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 } // namespace mfa

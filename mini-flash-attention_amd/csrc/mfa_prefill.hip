@@ -55,6 +55,13 @@ struct PrefillArgs {
     int32_t seqlens_k_offset; // added to seqlens_k[b]
     int32_t bottom_right;     // off = sk - sq (flash-attn >= 2.1 alignment) instead of 0 (the reference's top-left)
     float scale;              // softmax_scale (for the LSE)
+    // packed-row kv-cache attention (MQ kernels): the G query heads of a KV head x the seqlen_q query positions
+    // form ONE block of rows (row = position * G + head-in-group), keys are split over workgroups
+    int32_t mq_rows;          // seqlen_q * group
+    int32_t mq_row_blocks;    // ceil(mq_rows / BM)
+    int32_t num_splits;       // key splits; > 1: normalised partial O and LSE go to o_acc / lse_acc
+    float* o_acc;             // (splits, B, Sq, H, D) fp32
+    float* lse_acc;           // (splits, B, Sq, H) fp32
 };
 
 constexpr int kBN = 64; // keys per tile
@@ -83,7 +90,13 @@ __device__ __forceinline__ int v_swz(int row) {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
-template <typename T, int D, int NW, bool PAGED, int ABL = 0>
+// MQ = false: one workgroup per (batch, query head, block of BM query rows): prefill.
+// MQ = true : one workgroup per (batch, KV head, key split, block of BM PACKED rows), row = query position * G +
+//   head within the group: kv-cache attention with few query positions (speculative / chunked decoding, seqlen_q
+//   of 1..a few dozen) or a large GQA group, where one query head alone would leave the 32-row MFMA tiles almost
+//   empty and every head would re-stream the same K/V.  Same tile loop; only the row -> (position, head) mapping,
+//   the key range (a split) and the destination (final O, or normalised partials for decode_combine_kernel) differ.
+template <typename T, int D, int NW, bool PAGED, int ABL = 0, bool MQ = false>
 __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
     using E = Elem<T>;
     using frag8 = typename E::frag8;
@@ -117,27 +130,47 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // consecutive workgroups carry EQUAL work: the dispatcher deals consecutive workgroups round-robin over the
     // XCD's shader engines, and a heavy-to-light sequence inside one pair lands the heavy blocks on the same
     // engines every time (measured: 70 % wave-slot occupancy with pair-major order vs 94 % non-causal).
-    const int nmb = a.num_m_blocks;
-    const int npairs = a.batch * a.heads;
-    const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int p8 = npairs >> 3, r8 = npairs & 7;
-    const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
-    const int pair_count = p8 + (x < r8 ? 1 : 0);
-    const int gp = a.group_pairs;
-    const int g = k / (gp * nmb), t = k - g * (gp * nmb);
-    const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
-    if (gsize <= 0) return;
-    const int rank = t / gsize, pi = t - rank * gsize;
-    if (rank >= nmb) return; // padding of a short group
-    const int bh = pair_begin + g * gp + pi;
-    const int mblk = nmb - 1 - rank; // heaviest causal blocks first
-    const int hq = bh % a.heads;
-    const int b = bh / a.heads;
-    const int hk = hq / a.group;
+    int b, hq, hk, m0, split = 0;
+    if constexpr (!MQ) {
+        const int nmb = a.num_m_blocks;
+        const int npairs = a.batch * a.heads;
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int p8 = npairs >> 3, r8 = npairs & 7;
+        const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
+        const int pair_count = p8 + (x < r8 ? 1 : 0);
+        const int gp = a.group_pairs;
+        const int g = k / (gp * nmb), t = k - g * (gp * nmb);
+        const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
+        if (gsize <= 0) return;
+        const int rank = t / gsize, pi = t - rank * gsize;
+        if (rank >= nmb) return; // padding of a short group
+        const int bh = pair_begin + g * gp + pi;
+        const int mblk = nmb - 1 - rank; // heaviest causal blocks first
+        hq = bh % a.heads;
+        b = bh / a.heads;
+        hk = hq / a.group;
+        m0 = mblk * BM;
+    } else {
+        // XCD x owns a contiguous range of (batch, KV head) pairs; inside it: pair, split, row block (fastest)
+        const int npairs = a.batch * a.kv_heads;
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int p8 = npairs >> 3, r8 = npairs & 7;
+        const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
+        const int pair_count = p8 + (x < r8 ? 1 : 0);
+        const int per_pair = a.num_splits * a.mq_row_blocks;
+        const int pi = k / per_pair, t = k - pi * per_pair;
+        if (pi >= pair_count) return;
+        const int bk = pair_begin + pi;
+        b = bk / a.kv_heads;
+        hk = bk - b * a.kv_heads;
+        split = t / a.mq_row_blocks;
+        m0 = (t - split * a.mq_row_blocks) * BM; // first PACKED row of this block
+        hq = hk * a.group;                       // first query head of the group
+    }
 
     int sq, sk;
     int64_t q_off, o_off, k_off, v_off;
-    if (a.cu_q) {
+    if (!MQ && a.cu_q) {
         const int q0 = a.cu_q[b], k0 = a.cu_k[b];
         sq = a.cu_q[b + 1] - q0;
         sk = a.cu_k[b + 1] - k0;
@@ -153,8 +186,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         k_off = a.block_table ? 0 : b * a.k_batch_stride;
         v_off = a.block_table ? 0 : b * a.v_batch_stride;
     }
-    const int m0 = mblk * BM;
-    if (m0 >= sq) return; // whole workgroup, before any barrier
+    const int nrows = MQ ? a.mq_rows : sq; // rows of the (batch, head) / (batch, KV head) this block is cut from
+    if (m0 >= nrows) return; // whole workgroup, before any barrier
 
     const char* qbase = (const char*)a.q + 2 * (q_off + (int64_t)hq * a.q_head_stride);
     const char* kbase = (const char*)a.k + 2 * (k_off + (int64_t)hk * a.k_head_stride);
@@ -162,7 +195,17 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     char* obase = (char*)a.o + 2 * (o_off + (int64_t)hq * a.o_head_stride);
     const int32_t* table = a.block_table ? a.block_table + b * a.table_batch_stride : nullptr;
 
-    // key window of query row r: [r + lo, r + hi] intersected with [0, sk)  (top-left: off = 0, the reference's
+    // row -> query position (what the masks see) and byte offset from qbase / obase.  Prefill: the row IS the
+    // position.  MQ: row = position * G + head-in-group.
+    const int G = MQ ? a.group : 1;
+    auto row_pos = [&](int row) { return MQ ? row / G : row; };
+    auto row_off = [&](int row, int64_t row_stride, int64_t head_stride) -> int64_t {
+        if constexpr (!MQ) return (int64_t)row * row_stride;
+        const int pos = row / G;
+        return (int64_t)pos * row_stride + (int64_t)(row - pos * G) * head_stride;
+    };
+
+    // key window of query position r: [r + lo, r + hi] intersected with [0, sk)  (top-left: off = 0, the reference's
     // alignment, prefill.cuh:416-419; bottom-right: off = sk - sq)
     const int off = a.bottom_right ? sk - sq : 0;
     const bool has_hi = a.has_hi, has_lo = a.has_lo;
@@ -170,18 +213,23 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // key tiles this workgroup visits: [j_lo, j_lo + nt)
     int j_lo = 0, nt;
     {
-        const int last_row = min(m0 + BM, sq) - 1;
-        const int hi_key = has_hi ? min(sk - 1, last_row + hi) : sk - 1;
+        const int last_pos = row_pos(min(m0 + BM, nrows) - 1);
+        const int hi_key = has_hi ? min(sk - 1, last_pos + hi) : sk - 1;
         const int j_hi = hi_key >= 0 ? hi_key / kBN + 1 : 0;
-        if (has_lo) j_lo = min(max(m0 + lo, 0) / kBN, j_hi);
+        if (has_lo) j_lo = min(max(row_pos(m0) + lo, 0) / kBN, j_hi);
         nt = j_hi - j_lo;
+        if constexpr (MQ) { // this split's share of the tiles (possibly none: it still writes an empty partial)
+            const int per = (nt + a.num_splits - 1) / a.num_splits;
+            j_lo += split * per;
+            nt = max(min(per, j_hi - j_lo), 0);
+        }
     }
 
     // ---- Q fragments (B operand of S^T = K.Q^T): row m0+32*wave+r, columns 16*ks + 8h .. +7 -------
     const int qrow = m0 + 32 * wave + r;
     frag8 qf[KS];
     {
-        const char* qp = qbase + 2 * ((int64_t)min(qrow, sq - 1) * a.q_row_stride) + 16 * h;
+        const char* qp = qbase + 2 * row_off(min(qrow, nrows - 1), a.q_row_stride, a.q_head_stride) + 16 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const frag8*)(qp + 32 * ks);
     }
@@ -291,6 +339,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
 
     const float c = a.scale_log2;
     const int wrow0 = m0 + 32 * wave; // first query row of this wave
+    // query positions of this lane's row and of the wave's first / last row (prefill: the rows themselves)
+    const int qpos = row_pos(min(qrow, nrows - 1));
+    const int wpos_lo = row_pos(min(wrow0, nrows - 1)), wpos_hi = row_pos(min(wrow0 + 31, nrows - 1));
+    const bool wave_has_rows = wrow0 < nrows;
 
     load_pids(j_lo);
     if (nt > 0 && sk > 0) stage_dma(j_lo, std::integral_constant<int, 0>{});
@@ -314,7 +366,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         const bool dma = more && !(ABL & 1);
 
         // a wave none of whose rows can see this tile (above the causal diagonal / outside the window) skips it
-        const bool active = (!has_hi || j * kBN <= wrow0 + 31 + hi) && (!has_lo || j * kBN + kBN - 1 >= wrow0 + lo);
+        const bool active = (!MQ || wave_has_rows) && (!has_hi || j * kBN <= wpos_hi + hi) &&
+                            (!has_lo || j * kBN + kBN - 1 >= wpos_lo + lo);
         if (!active && dma) stage_dma(j + 1, nbuf);
         if (!active) load_pids(j + 2);
         if (active) {
@@ -353,9 +406,9 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             load_pids(j + 2); // (paged) consumed by the next tile's DMA, after this tile's end-of-tile wait
             // mask: key > row + hi (causal: hi = 0, top-left) or key >= sk; register i of block kb is key
             // j*64 + 4h + (32*kb + (i&3) + 8*(i>>2))
-            const bool need_mask = (has_hi && j * kBN + kBN - 1 > wrow0 + hi) || (j + 1) * kBN > sk;
+            const bool need_mask = (has_hi && j * kBN + kBN - 1 > wpos_lo + hi) || (j + 1) * kBN > sk;
             if (need_mask) {
-                const int lim = (has_hi ? min(qrow + hi, sk - 1) : sk - 1) - j * kBN - 4 * h; // keys <= lim stay
+                const int lim = (has_hi ? min(qpos + hi, sk - 1) : sk - 1) - j * kBN - 4 * h; // keys <= lim stay
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -363,8 +416,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                         if (32 * kb + (i & 3) + 8 * (i >> 2) > lim) s[kb][i] = -INFINITY;
             }
             // sliding window: key < row + lo
-            if (has_lo && j * kBN < wrow0 + 31 + lo) {
-                const int liml = qrow + lo - j * kBN - 4 * h; // keys >= liml stay
+            if (has_lo && j * kBN < wpos_hi + lo) {
+                const int liml = qpos + lo - j * kBN - 4 * h; // keys >= liml stay
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -446,11 +499,30 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
     const float l_tot = l_run + swap32(l_run);
     const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
-    if (!(ABL & 1024) && a.lse && h == 0 && qrow < sq) { // natural-log LSE of the scaled scores; -inf for a row that saw no key
-        const float lse = l_tot > 0.f ? m_run * a.scale + __logf(l_tot) : -INFINITY;
+    const float lse_row = l_tot > 0.f ? m_run * a.scale + __logf(l_tot) : -INFINITY; // natural log, -inf: no key seen
+    if constexpr (MQ) {
+        const int grp = qrow - qpos * G; // head within the group (rows past the block: unused)
+        if (a.num_splits > 1) {
+            // normalised partial of this key split, fp32, straight from the accumulators: (split, B, Sq, H) rows
+            if (qrow < nrows) {
+                const int64_t arow = (((int64_t)split * a.batch + b) * sq + qpos) * a.heads + hq + grp;
+                if (h == 0) a.lse_acc[arow] = lse_row;
+                float* op = a.o_acc + arow * D + 4 * h;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        f32x4 w = {oacc[d][4 * g4] * inv, oacc[d][4 * g4 + 1] * inv, oacc[d][4 * g4 + 2] * inv, oacc[d][4 * g4 + 3] * inv};
+                        *(f32x4*)(op + 32 * d + 8 * g4) = w;
+                    }
+            }
+            return;
+        }
+        if (a.lse && h == 0 && qrow < nrows) a.lse[((int64_t)b * a.heads + hq + grp) * sq + qpos] = lse_row;
+    } else if (!(ABL & 1024) && a.lse && h == 0 && qrow < sq) {
         const int64_t idx = a.cu_q ? (int64_t)hq * a.total_q + a.cu_q[b] + qrow
                                    : ((int64_t)b * a.heads + hq) * a.seqlen_q + qrow;
-        a.lse[idx] = lse;
+        a.lse[idx] = lse_row;
     }
     // the loop's last barrier guarantees every wave is done with the K/V buffers
     char* so = smem + wave * 32 * RB; // this wave's 32 rows x RB bytes
@@ -474,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             const int rr = it * ROWS_PER_IT + rr0;
             const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
             const int grow = wrow0 + rr;
-            if (grow < sq) *(u32x4*)(obase + 2 * ((int64_t)grow * a.o_row_stride) + 16 * ch) = val;
+            if (grow < nrows) *(u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch) = val;
         }
     } else {
         // CH does not divide 64 (D = 96, 160, ...): walk the 32*CH chunks of the wave linearly
@@ -482,7 +554,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             const int rr = idx / CH, ch = idx - rr * CH;
             const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
             const int grow = wrow0 + rr;
-            if (grow < sq) *(u32x4*)(obase + 2 * ((int64_t)grow * a.o_row_stride) + 16 * ch) = val;
+            if (grow < nrows) *(u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch) = val;
         }
     }
     if constexpr ((ABL & 1024) != 0) {
@@ -563,7 +635,7 @@ static int launch_prefill_d(PrefillArgs& a, hipStream_t stream) {
     }
 }
 
-int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
+static PrefillArgs make_args(const mfa_forward_params& p) {
     PrefillArgs a{};
     a.q = p.q_ptr; a.k = p.k_ptr; a.v = p.v_ptr; a.o = p.o_ptr;
     a.cu_q = p.cu_seqlens_q; a.cu_k = p.cu_seqlens_k; a.block_table = p.block_table;
@@ -595,7 +667,54 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     }
     a.has_hi = wr >= 0; a.hi_off = wr >= 0 ? wr : 0;
     a.has_lo = wl >= 0; a.lo_off = wl >= 0 ? -wl : 0;
+    return a;
+}
+
+int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
+    PrefillArgs a = make_args(p);
     return p.is_bf16 ? launch_prefill_d<BFloat>(a, stream) : launch_prefill_d<Half>(a, stream);
+}
+
+// ---- packed-row kv-cache attention ---------------------------------------------------------------------------
+template <typename T, int D, bool PAGED>
+static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
+    constexpr int NW = 4, BM = 32 * NW;
+    constexpr int RB = Pitch<D>::RB;
+    constexpr size_t smem = 4 * kBN * RB;
+    a.mq_rows = a.seqlen_q * a.group;
+    a.mq_row_blocks = (a.mq_rows + BM - 1) / BM;
+    const int64_t npairs = (int64_t)a.batch * a.kv_heads;
+    if (npairs <= 0 || a.mq_rows <= 0) return 0;
+    const int64_t total = 8 * ((npairs + 7) / 8) * a.num_splits * a.mq_row_blocks;
+    if (total > 0x7fffffffLL) return -1;
+    auto kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true>;
+    if (smem > 64 * 1024 &&
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+        return -3;
+    hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(64 * NW), smem, stream, a);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T>
+static int launch_mq_d(PrefillArgs& a, hipStream_t stream) {
+    const bool paged = a.block_table != nullptr;
+    switch (a.head_dim) { // the head dims serving stacks use; others take the per-head prefill path (caller's fallback)
+    case 64: return paged ? launch_mq_p<T, 64, true>(a, stream) : launch_mq_p<T, 64, false>(a, stream);
+    case 128: return paged ? launch_mq_p<T, 128, true>(a, stream) : launch_mq_p<T, 128, false>(a, stream);
+    case 256: return paged ? launch_mq_p<T, 256, true>(a, stream) : launch_mq_p<T, 256, false>(a, stream);
+    default: return -2;
+    }
+}
+
+int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream) {
+    PrefillArgs a = make_args(p);
+    a.cu_q = a.cu_k = nullptr;
+    a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
+    a.o_acc = p.oaccum_ptr;
+    a.lse_acc = p.softmax_lseaccum_ptr;
+    const int rc = p.is_bf16 ? launch_mq_d<BFloat>(a, stream) : launch_mq_d<Half>(a, stream);
+    if (rc) return rc;
+    return a.num_splits > 1 ? launch_decode_combine(p, stream) : 0;
 }
 
 } // namespace mfa

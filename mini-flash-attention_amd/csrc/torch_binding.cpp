@@ -86,6 +86,26 @@ void set_paged(mfa_forward_params& p, const at::Tensor& block_table, const at::T
     p.v_cache_block_stride = v.stride(0);
 }
 
+// kv-cache launch: asks the library for its key-split count and workspace sizes (reference:
+// forward_params_set_split_kv, api.cpp:305-340; the kernels write -inf LSE for empty splits themselves, so no fill
+// kernel is launched), allocates them from the caching allocator and runs.
+static void run_kvcache(mfa_forward_params& p, const at::Tensor& q, int requested_splits) {
+    p.num_splits = requested_splits;
+    int splits = 1;
+    size_t o_bytes = 0, lse_bytes = 0;
+    check_rc(mfa_kvcache_plan(&p, &splits, &o_bytes, &lse_bytes));
+    p.num_splits = splits;
+    at::Tensor lse_accum, out_accum;
+    if (splits > 1) {
+        auto opts = q.options().dtype(at::kFloat);
+        lse_accum = at::empty({static_cast<int64_t>(lse_bytes / sizeof(float))}, opts);
+        out_accum = at::empty({static_cast<int64_t>(o_bytes / sizeof(float))}, opts);
+        p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
+        p.oaccum_ptr = out_accum.data_ptr<float>();
+    }
+    check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
+}
+
 // reference: mfa::flash_attention_forward, csrc/mfa/api.cpp:113-186
 at::Tensor flash_attention_forward(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v,
                                    std::optional<at::Tensor> out_, bool is_causal, int window_size_left,
@@ -245,17 +265,7 @@ at::Tensor mha_fwd_kvcache(const at::Tensor& q, const at::Tensor& k_cache, const
     at::Tensor softmax_lse = at::empty({batch, num_heads}, opts);
     p.softmax_lse_ptr = softmax_lse.data_ptr<float>();
 
-    // split choice + workspaces (reference: forward_params_set_split_kv, api.cpp:305-340); the kernel
-    // writes -inf LSE for empty splits itself, so no fill kernel is launched.
-    p.num_splits = mfa_num_splits_heuristic(num_splits, batch, kv_num_heads, seqlen_k, 0);
-    at::Tensor lse_accum, out_accum;
-    if (p.num_splits > 1) {
-        lse_accum = at::empty({p.num_splits, batch, num_heads}, opts);
-        out_accum = at::empty({p.num_splits, batch, num_heads, head_dim}, opts);
-        p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
-        p.oaccum_ptr = out_accum.data_ptr<float>();
-    }
-    check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
+    run_kvcache(p, q, num_splits);
     return out;
 }
 
@@ -441,33 +451,15 @@ OutLse kvcache_ex(const at::Tensor& q, const at::Tensor& k_cache, const at::Tens
     p.seqlens_k_offset = appended;
     auto opts = q.options().dtype(at::kFloat);
     std::optional<at::Tensor> lse;
-    const bool windowed = window_left >= 0 || window_right >= 0;
-    if (seqlen_q == 1 && !windowed) {
-        // single-token decode: causal cannot mask anything (the query is the last position)
-        set_windows(p, -1, -1, seqlen_k);
-        at::Tensor softmax_lse = at::empty({batch, num_heads}, opts);
-        p.softmax_lse_ptr = softmax_lse.data_ptr<float>();
-        p.num_splits = mfa_num_splits_heuristic(num_splits, batch, kv_num_heads, seqlen_k, 0);
-        at::Tensor lse_accum, out_accum;
-        if (p.num_splits > 1) {
-            lse_accum = at::empty({p.num_splits, batch, num_heads}, opts);
-            out_accum = at::empty({p.num_splits, batch, num_heads, head_dim}, opts);
-            p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
-            p.oaccum_ptr = out_accum.data_ptr<float>();
-        }
-        check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
-        if (return_lse) lse = softmax_lse.unsqueeze(-1);
-    } else {
-        // several query tokens against the cache (speculative / chunked decoding): the MFMA path, with the mask
-        // aligned to the last key (query i is position seqlens_k[b] + appended - seqlen_q + i)
-        set_windows(p, -1, causal ? 0 : -1, seqlen_k);
-        set_extras(p, window_left, window_right, true);
-        if (return_lse) {
-            lse = at::empty({batch, num_heads, seqlen_q}, opts);
-            p.softmax_lse_ptr = lse->data_ptr<float>();
-        }
-        check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
-    }
+    // one entry for every seqlen_q: the library picks flash decoding (Sq = 1, small GQA group), the packed-row MFMA
+    // kernel (a few query tokens and / or a large group) or the per-head prefill kernel (long query blocks); the
+    // queries are the last seqlen_q positions, so causal / windows align to the last key
+    set_windows(p, -1, causal ? 0 : -1, seqlen_k);
+    set_extras(p, window_left, window_right, true);
+    at::Tensor softmax_lse = at::empty({batch, num_heads, seqlen_q}, opts);
+    p.softmax_lse_ptr = softmax_lse.data_ptr<float>();
+    run_kvcache(p, q, num_splits);
+    if (return_lse) lse = softmax_lse;
     return {out, lse};
 }
 

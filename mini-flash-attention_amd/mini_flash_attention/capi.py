@@ -90,6 +90,8 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.mfa_num_splits_heuristic.restype = ctypes.c_int
     lib.mfa_decode_workspace_bytes.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_size_t)] * 2
     lib.mfa_decode_workspace_bytes.restype = None
+    lib.mfa_kvcache_plan.argtypes = [P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    lib.mfa_kvcache_plan.restype = ctypes.c_int
     lib.mfa_device_cu_count.argtypes = [ctypes.c_int]
     lib.mfa_device_cu_count.restype = ctypes.c_int
     _lib = lib

@@ -111,8 +111,10 @@ def test_argument_validation_without_launch(capi, oracle):
         assert msg in capi.last_error(), (over, capi.last_error())
     p = _params(capi, oracle, q_ptr=_params(capi, oracle).q_ptr + 2)
     assert fwd(ctypes.byref(p), None) == capi.MFA_ERR_INVALID_ARGUMENT and "16-byte" in capi.last_error()
-    p = _params(capi, oracle)  # seqlen_q = 64
-    assert dec(ctypes.byref(p), None) == capi.MFA_ERR_INVALID_ARGUMENT and "seqlen_q == 1" in capi.last_error()
+    p = _params(capi, oracle, seqlen_q=0)
+    assert dec(ctypes.byref(p), None) == capi.MFA_ERR_INVALID_ARGUMENT and "seqlen_q must be >= 1" in capi.last_error()
+    p = _params(capi, oracle, seqlen_q=4, cu_seqlens_q=64, cu_seqlens_k=64)
+    assert dec(ctypes.byref(p), None) == capi.MFA_ERR_INVALID_ARGUMENT and "packed sequences" in capi.last_error()
     p = _params(capi, oracle, seqlen_q=1, num_splits=4)
     assert dec(ctypes.byref(p), None) == capi.MFA_ERR_WORKSPACE
     # empty problems succeed without touching the device
@@ -159,3 +161,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "capi.py" and "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_kvcache_plan_without_device(capi, oracle):
+    """mfa_kvcache_plan is host arithmetic: routes, split counts and workspace sizes can be checked without a GPU
+    (num_cus given, so nothing queries the device)."""
+    lib = capi.load()
+    s, ob, lb = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+
+    def plan(**kw):
+        p = _params(capi, oracle, **kw)
+        p.num_cus = 256
+        assert lib.mfa_kvcache_plan(ctypes.byref(p), ctypes.byref(s), ctypes.byref(ob), ctypes.byref(lb)) == capi.MFA_OK
+        return s.value, ob.value, lb.value
+
+    # flash decoding with a small group: exactly the decode heuristic and its workspace formula
+    n, o, l = plan(batch=24, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=8192, head_dim=128, num_splits=0)
+    assert n == lib.mfa_num_splits_heuristic(0, 24, 8, 8192, 256)
+    assert (o, l) == ((n * 24 * 24 * 128 * 4, n * 24 * 24 * 4) if n > 1 else (0, 0))
+    # a few query tokens: packed kernel; few (batch, KV head) pairs on 512 workgroup slots must be split
+    n, o, l = plan(batch=4, seqlen_q=8, heads=32, kv_heads=8, seqlen_k=65536, head_dim=128, num_splits=0)
+    assert 8 <= n <= 128 and (o, l) == (n * 4 * 8 * 32 * 128 * 4, n * 4 * 8 * 32 * 4)
+    # plenty of pairs: no split, no workspace
+    assert plan(batch=256, seqlen_q=2, heads=32, kv_heads=8, seqlen_k=512, head_dim=128, num_splits=0) == (1, 0, 0)
+    # explicit requests are honoured up to the number of 64-key tiles
+    assert plan(batch=2, seqlen_q=4, heads=32, kv_heads=8, seqlen_k=256, head_dim=128, num_splits=64)[0] == 4
+    # long query blocks run the per-head prefill kernel unsplit
+    assert plan(batch=2, seqlen_q=1024, heads=32, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=8) == (1, 0, 0)
+    p = _params(capi, oracle, heads=8, kv_heads=3)
+    assert lib.mfa_kvcache_plan(ctypes.byref(p), None, None, None) == capi.MFA_ERR_INVALID_ARGUMENT
