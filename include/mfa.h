@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 2
+#define MFA_ABI_VERSION 3
 
 enum {
     MFA_OK = 0,

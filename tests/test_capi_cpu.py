@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(capi):
     assert {"mfa_run_flash_attention_forward", "mfa_run_flash_attention_with_kv_cache", "mfa_num_splits_heuristic"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"libmfa_hip.so does not export {n}"
-    assert lib.mfa_abi_version() == 2
+    assert lib.mfa_abi_version() == 3
     assert b"gfx950" in lib.mfa_version()
 
 
