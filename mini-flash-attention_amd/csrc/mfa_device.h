@@ -134,14 +134,28 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 // ds_read_b64_tr_b16 of the tile, i.e. half a tile after it was issued.  In asm the compiler does not track it:
 // the CALLER must retire it with s_waitcnt vmcnt(N) and a workgroup barrier before any wave reads the bytes.
 // M0 is written in the same statement that consumes it and is not used by anything else in these kernels.
+// NT = the non-temporal cache policy: for data read once (a K/V cache being streamed) it lifts the achievable HBM
+// rate from 5.8-6.0 to 6.8-6.9 TB/s (tools/probes/stream_probe.hip); for tiles that other workgroups re-read out of
+// L2 (prefill) the default policy is the right one.
+template <bool NT = false>
 __device__ __forceinline__ void lds_dma16(const char* wave_uniform_base, uint32_t lane_byte_offset, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :
-                 : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_addr)
-                 : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                     :
+                     : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_addr)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :
+                     : "v"(lane_byte_offset), "s"(wave_uniform_base), "s"(lds_addr)
+                     : "memory");
 }
+template <bool NT = false>
 __device__ __forceinline__ void lds_dma16(const char* lane_ptr, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(lane_ptr), "s"(lds_addr) : "memory");
+    if constexpr (NT)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(lane_ptr), "s"(lds_addr) : "memory");
+    else
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(lane_ptr), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ uint32_t lds_address(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;

@@ -96,7 +96,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 //   of 1..a few dozen) or a large GQA group, where one query head alone would leave the 32-row MFMA tiles almost
 //   empty and every head would re-stream the same K/V.  Same tile loop; only the row -> (position, head) mapping,
 //   the key range (a split) and the destination (final O, or normalised partials for decode_combine_kernel) differ.
-template <typename T, int D, int NW, bool PAGED, int ABL = 0, bool MQ = false, bool RS = false>
+template <typename T, int D, int NW, bool PAGED, int ABL = 0, bool MQ = false, bool STREAM = false>
 __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
     using E = Elem<T>;
     using frag8 = typename E::frag8;
@@ -246,11 +246,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     constexpr int RPI = 64 / LPR_;           // rows per wave-instruction
     constexpr int NI = kBN / (RPI * NW) > 0 ? kBN / (RPI * NW) : 1; // instructions per wave per tile (K, and V)
     static_assert(kBN % (RPI * NW) == 0 || kBN / (RPI * NW) == 0, "tile rows must split evenly over the waves");
-    // REG_STAGE (packed-row kernels with at most 128 rows on a dense cache): the next tile travels global -> VGPR ->
-    // LDS instead of by LDS-DMA.  Those launches stream (one or two waves compute); LDS-DMA tops out at 5.8-6.0 TB/s
-    // on this part while plain 16-byte loads reach 6.5-6.9 (tools/probes/stream_probe.hip): +7-13 % measured.  With
-    // more rows the MFMA work dominates and the DMA (no VGPRs, no ds_write issue slots) is the better carrier.
-    constexpr bool REG_STAGE = RS; // chosen by the launcher: few packed rows (streaming-bound), dense cache, D <= 128
+    // STREAM (launcher's choice for packed-row launches with ONE row block, where every K/V byte is read exactly
+    // once): the DMA uses the non-temporal policy, which lifts the achievable HBM rate from 5.8-6.0 to 6.8-6.9 TB/s
+    // (tools/probes/stream_probe.hip).  Prefill, and packed launches whose row blocks re-read K/V out of L2, keep the
+    // default policy (prefill with nt: -20...-30 %).
+    constexpr bool DMA_NT = STREAM || (ABL & 2048) != 0;
     const int last_key = max(sk - 1, 0);
     const int srow = wave * RPI + lane / LPR_; // row of this lane inside instruction 0 (+ i*RPI*NW for instruction i)
     const int spos = lane % LPR_;
@@ -295,41 +295,22 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
             const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
             const int64_t pid = pid_n[is_v ? pc - NI : pc];
-            if (is_v) lds_dma16(vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch, dst);
-            else lds_dma16(kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row), dst);
+            if (is_v) lds_dma16<DMA_NT>(vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch, dst);
+            else lds_dma16<DMA_NT>(kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row), dst);
         } else {
             const uint32_t rows = (uint32_t)(j * kBN + row);
             if (is_v) {
-                lds_dma16(vbase, min(v_go + rows * v_sb, v_gmax), dst);
+                lds_dma16<DMA_NT>(vbase, min(v_go + rows * v_sb, v_gmax), dst);
             } else {
                 // (chunk delta of instruction i, a compile-time XOR pattern, when the K swizzle moves with i)
                 const int kd = KSWZ_FIXED ? 0 : 16 * (k_src_chunk(srow + row) - s_kch);
-                lds_dma16(kbase, min(k_go + rows * k_sb, k_gmax) + kd, dst);
+                lds_dma16<DMA_NT>(kbase, min(k_go + rows * k_sb, k_gmax) + kd, dst);
             }
         }
     };
     auto stage_dma = [&](int j, auto bufc) {
 #pragma unroll
         for (int pc = 0; pc < 2 * NI; ++pc) stage_piece(j, bufc, pc);
-    };
-    // REG_STAGE: the same pieces, same LDS image, through registers: issue at the top of a tile, write at its end
-    auto stage_load = [&](int j, u32x4 (&stg)[2 * NI]) {
-#pragma unroll
-        for (int pc = 0; pc < 2 * NI; ++pc) {
-            const bool is_v = pc >= NI;
-            const uint32_t rows = (uint32_t)(j * kBN + (is_v ? pc - NI : pc) * RPI * NW);
-            const char* src = is_v ? vbase + min(v_go + rows * v_sb, v_gmax) : kbase + min(k_go + rows * k_sb, k_gmax);
-            stg[pc] = __builtin_nontemporal_load((const u32x4*)src);
-        }
-    };
-    auto stage_store = [&](auto bufc, const u32x4 (&stg)[2 * NI]) {
-        constexpr int BUF = decltype(bufc)::value;
-#pragma unroll
-        for (int pc = 0; pc < 2 * NI; ++pc) {
-            const bool is_v = pc >= NI;
-            const int row = (is_v ? pc - NI : pc) * RPI * NW;
-            *(u32x4*)(smem + (is_v ? 2 * TILE_BYTES : 0) + BUF * TILE_BYTES + (row + wave * RPI) * RB + 16 * lane) = stg[pc];
-        }
     };
 
     // ---- per-lane LDS read addresses (bases; tile buffer, key block and k-step are immediates) ------
@@ -387,12 +368,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         // pieces are issued one per QK^T k-step, between the MFMAs, rather than as a burst: a burst of 1-KiB pieces
         // stalls the wave at issue (the price of a piece depends on what else is in flight).
         constexpr auto nbuf = std::integral_constant<int, BUF ^ 1>{};
-        const bool dma = more && !(ABL & 1) && !REG_STAGE;
-        u32x4 stg[2 * NI];
-        if constexpr (REG_STAGE) {
-            if (more) stage_load(j + 1, stg);
-            __builtin_amdgcn_sched_barrier(0); // keep the loads up here (hipcc would sink them to the stores below)
-        }
+        const bool dma = more && !(ABL & 1);
 
         // a wave none of whose rows can see this tile (above the causal diagonal / outside the window) skips it
         const bool active = (!MQ || wave_has_rows) && (!has_hi || j * kBN <= wpos_hi + hi) &&
@@ -513,12 +489,8 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 }
             }
         }
-        if constexpr (REG_STAGE) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) stage_store(nbuf, stg); // (the other buffer: every wave left it at the previous barrier)
-        }
         // the DMA is a pending LDS write on the VM counter: drain it, then let the other waves read the tile
-        if (!(ABL & 64) && !REG_STAGE) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        if (!(ABL & 64)) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
         if (!(ABL & 2)) __syncthreads();
     };
 
@@ -634,6 +606,7 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
         case 256: kern = prefill_fwd_kernel<T, D, NW, PAGED, 256>; break;
         case 512: kern = prefill_fwd_kernel<T, D, NW, PAGED, 512>; break;
         case 1024: kern = prefill_fwd_kernel<T, D, NW, PAGED, 1024>; break;
+        case 2048: kern = prefill_fwd_kernel<T, D, NW, PAGED, 2048>; break;
         default: break;
         }
     }
@@ -721,10 +694,8 @@ static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
     const int64_t total = 8 * ((npairs + 7) / 8) * a.num_splits * a.mq_row_blocks;
     if (total > 0x7fffffffLL) return -1;
     auto kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true, false>;
-    if constexpr (!PAGED && D <= 128) { // (head dim 256 has no registers to spare for the staging)
-        static const int env_rs = [] { const char* e = getenv("MFA_MQ_REG_STAGE"); return e ? atoi(e) : -1; }();
-        if (env_rs == 1 || (env_rs != 0 && a.mq_rows <= 128)) kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true, true>;
-    }
+    static const int env_nt = [] { const char* e = getenv("MFA_MQ_STREAM"); return e ? atoi(e) : -1; }();
+    if (env_nt == 1 || (env_nt != 0 && a.mq_row_blocks == 1)) kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true, true>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return -3;

@@ -10,6 +10,9 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void lds_dma16(const char* base, uint32_t off, uint32_t lds) {
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds) : "memory");
 }
+__device__ __forceinline__ void lds_dma16_nt(const char* base, uint32_t off, uint32_t lds) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" : : "v"(off), "s"(base), "s"(lds) : "memory");
+}
 
 // each workgroup (256 threads) streams `bytes_per_wg` contiguous bytes; DEPTH = 1-KiB pieces per wave in flight
 template <int MODE, int DEPTH>
@@ -22,11 +25,14 @@ __global__ __launch_bounds__(256, 2) void stream_kernel(const char* src, size_t 
     const char* wbase = base + wave * per_wave;
     const int steps = (int)(per_wave / (DEPTH * 1024));
     uint32_t acc = 0;
-    if (MODE == 0) {
+    if (MODE == 0 || MODE == 3) {
         for (int s = 0; s < steps; ++s) {
             u32x4 v[DEPTH];
 #pragma unroll
-            for (int d = 0; d < DEPTH; ++d) v[d] = __builtin_nontemporal_load((const u32x4*)(wbase + ((size_t)s * DEPTH + d) * 1024 + lane * 16));
+            for (int d = 0; d < DEPTH; ++d) {
+                const u32x4* ptr = (const u32x4*)(wbase + ((size_t)s * DEPTH + d) * 1024 + lane * 16);
+                v[d] = MODE == 0 ? __builtin_nontemporal_load(ptr) : *ptr;
+            }
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) acc ^= v[d][0] ^ v[d][1] ^ v[d][2] ^ v[d][3];
         }
@@ -37,7 +43,8 @@ __global__ __launch_bounds__(256, 2) void stream_kernel(const char* src, size_t 
 #pragma unroll
             for (int d = 0; d < DEPTH; ++d) {
                 const uint32_t lds = __builtin_amdgcn_readfirstlane(lds0 + (p * DEPTH + d) * 1024);
-                lds_dma16(wbase + ((size_t)s * DEPTH + d) * 1024, lane * 16, lds);
+                if (MODE == 2) lds_dma16_nt(wbase + ((size_t)s * DEPTH + d) * 1024, lane * 16, lds);
+                else lds_dma16(wbase + ((size_t)s * DEPTH + d) * 1024, lane * 16, lds);
             }
             // previous step's pieces: all but the DEPTH just issued
             if (DEPTH == 2) __builtin_amdgcn_s_waitcnt(0x0F72);
@@ -55,7 +62,7 @@ static void run(const char* name, const char* d, size_t total, uint32_t* sink, i
     const size_t per = total / wgs / 8192 * 8192;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
-    const size_t smem = MODE ? 4 * DEPTH * 2 * 1024 : 0;
+    const size_t smem = (MODE == 1 || MODE == 2) ? 4 * DEPTH * 2 * 1024 : 0;
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((stream_kernel<MODE, DEPTH>), dim3(wgs), dim3(256), smem, 0, d, per, sink);
     hipEventRecord(a);
     const int it = 10;
@@ -71,8 +78,10 @@ int main() {
     hipMalloc(&d, total); hipMalloc(&sink, 4);
     hipMemset(d, 1, total);
     for (int wgs : {256, 512, 1024, 2048}) {
-        run<0, 4>("global_load x4 (regs), depth 4", d, total, sink, wgs);
-        run<0, 8>("global_load x4 (regs), depth 8", d, total, sink, wgs);
+        run<0, 4>("global_load x4 nt (regs), depth 4", d, total, sink, wgs);
+        run<0, 8>("global_load x4 nt (regs), depth 8", d, total, sink, wgs);
+        run<3, 8>("global_load x4 (regs), depth 8", d, total, sink, wgs);
+        run<2, 4>("LDS-DMA x4 nt, depth 4+4", d, total, sink, wgs);
         run<1, 2>("LDS-DMA x4, depth 2+2", d, total, sink, wgs);
         run<1, 4>("LDS-DMA x4, depth 4+4", d, total, sink, wgs);
         run<1, 8>("LDS-DMA x4, depth 8+8", d, total, sink, wgs);
