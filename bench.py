@@ -177,6 +177,22 @@ def main():
                      "algorithmic_bytes": decode_bytes(d)},
     }
 
+    # beside the two BASELINE shapes: the packed-row kv-cache kernel on a GQA group of 8 (same cache, 64 query heads)
+    del qd
+    qg = torch.randn(d["B"], 1, 8 * d["Hk"], d["D"], device=dev, dtype=torch.float32).to(d["dtype"])
+    g8 = dict(d, H=8 * d["Hk"])
+    gwall, gev_ms = timed_region(lambda: mfa.flash_attn_with_kvcache(qg, kc, vc, cache_seqlens=lens, num_splits=0),
+                                 args.steps, args.warmup, dist)
+    packed = {
+        "metric": "decode HBM GB/s, GQA group 8 (packed-row MFMA kernel)", "value": round(decode_bytes(g8) * n_gpus * args.steps / gwall / 1e9, 1),
+        "unit": "GB/s", "us_per_step": round(gwall / args.steps * 1e6, 2), "dtype": "bf16",
+        "config": {"workload": "kv-cache attention bf16 B=24 Sq=1 Skv=8192 Hq=64 Hkv=8 D=128 num_splits=auto"},
+        "roofline": {"bound": "hbm", "achieved": round(decode_bytes(g8) / (gev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                     "frac": round(decode_bytes(g8) / (gev_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
+                     "kernel": "prefill_fwd_kernel<MQ> + decode_combine_kernel", "kernel_us": round(gev_ms * 1e3, 2),
+                     "algorithmic_bytes": decode_bytes(g8)},
+    }
+
     if rank == 0:
         out = {
             "metric": "prefill attention TFLOPS (fp16, head_dim=128, causal) + decode HBM GB/s, 1xMI355X",
@@ -185,7 +201,7 @@ def main():
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "prefill fp16 B=48 S=1024 H=24 D=128 causal per GPU (BASELINE config 2, benchmark/prefill.py shape)",
                        "parallelism": f"replicas x{n_gpus} (no collective on the data path)"},
-            "roofline": roof, "decode": decode,
+            "roofline": roof, "decode": decode, "kvcache_packed": packed,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)

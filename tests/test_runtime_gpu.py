@@ -33,7 +33,8 @@ def test_side_stream_ordering(mfa):
 
 
 def test_hip_graph_capture_and_replay(mfa):
-    """Prefill, split decode (+ combine) and append captured into one graph; replay with new inputs in the same buffers."""
+    """Prefill, split decode (+ combine), append and the packed-row kv-cache kernel (3 query tokens, split) captured
+    into one graph; replay with new inputs in the same buffers."""
     B, S, H, Hk, D = 2, 256, 8, 2, 128
     q = rnd(B, S, H, D, seed=1)
     k, v = rnd(B, S, Hk, D, seed=2), rnd(B, S, Hk, D, seed=3)
@@ -41,22 +42,29 @@ def test_hip_graph_capture_and_replay(mfa):
     kc, vc = rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=5), rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=6)
     kn, vn = rnd(B, 1, Hk, D, dtype=torch.bfloat16, seed=7), rnd(B, 1, Hk, D, dtype=torch.bfloat16, seed=8)
     lens = torch.tensor([2000, 777], dtype=torch.int32, device=DEV)
+    qs = rnd(B, 3, H, D, dtype=torch.bfloat16, seed=9)
     # warm-up outside capture (lazy module/attribute initialisation)
     mfa.flash_attn_func(q, k, v, causal=True)
     mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=4, k=kn, v=vn)
+    mfa.flash_attn_with_kvcache(qs, kc, vc, cache_seqlens=lens, causal=True, num_splits=3)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         o1 = mfa.flash_attn_func(q, k, v, causal=True)
         o2 = mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=4, k=kn, v=vn)
+        o3 = mfa.flash_attn_with_kvcache(qs, kc, vc, cache_seqlens=lens, causal=True, num_splits=3)
     for seed in (11, 12):
         q.copy_(rnd(B, S, H, D, seed=seed))
         qd.copy_(rnd(B, 1, H, D, dtype=torch.bfloat16, seed=seed + 100))
         g.replay()
         torch.cuda.synchronize()
         assert_close(o1, hp.sdpa_gpu(q, k, v, True), what="graph prefill")
+        qs.copy_(rnd(B, 3, H, D, dtype=torch.bfloat16, seed=seed + 200))
+        g.replay()
+        torch.cuda.synchronize()
         eager = mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=4, k=kn, v=vn)
         assert torch.equal(o2, eager)
+        assert torch.equal(o3, mfa.flash_attn_with_kvcache(qs, kc, vc, cache_seqlens=lens, causal=True, num_splits=3))
 
 
 def test_thread_local_errors_and_concurrent_calls(mfa, capi):
