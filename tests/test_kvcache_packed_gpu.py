@@ -130,3 +130,18 @@ def test_c_abi_plan_and_forced_splits(capi):
         assert lib.mfa_run_flash_attention_with_kv_cache(ctypes.byref(p), stream) == 0, capi.last_error()
         torch.cuda.synchronize()
         close(o, ref, f"C ABI splits={s.value}")
+
+
+def test_strided_queries_and_caches(mfa):
+    """q is a slice of a wider tensor (row / batch strides larger than the packed shape), the cache a slice of a longer
+    one with more heads: the packed kernel must take every stride from the parameter block."""
+    B, Sq, Hq, Hk, Sk, D = 3, 4, 16, 2, 600, 128
+    q_wide = rnd(B, Sq + 2, Hq + 8, D, seed=22)
+    q = q_wide[:, 1:1 + Sq, 4:4 + Hq]
+    kc_wide, vc_wide = rnd(B + 1, Sk + 40, Hk + 1, D, seed=23), rnd(B + 1, Sk + 40, Hk + 1, D, seed=24)
+    kc, vc = kc_wide[1:, 8:8 + Sk, :Hk], vc_wide[1:, 8:8 + Sk, 1:]
+    assert not q.is_contiguous() and not kc.is_contiguous()
+    lens = torch.tensor([600, 77, 300], dtype=torch.int32, device=DEV)
+    ours = mfa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True)
+    theirs = fa.flash_attn_with_kvcache(q.contiguous(), kc.contiguous(), vc.contiguous(), cache_seqlens=lens, causal=True)
+    close(ours, theirs, "strided q / cache")
