@@ -121,7 +121,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    # (MFA_BENCH_FORCE_DIST=1: take the RCCL path with a single rank, to rehearse it on a one-GPU box)
+    dist = world > 1 or os.environ.get("MFA_BENCH_FORCE_DIST") == "1"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
