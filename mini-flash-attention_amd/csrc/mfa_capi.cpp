@@ -190,8 +190,8 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
 }
 
 // Which kernel serves a kv-cache call (the dispatch of mfa_run_flash_attention_with_kv_cache and of mfa_kvcache_plan):
-//   kKvDecode  seqlen_q == 1 and a GQA group of at most 4: the vector kernel of mfa_decode.hip (every K/V byte once,
-//              G heads in registers; 73-78 % of HBM peak);
+//   kKvDecode  seqlen_q == 1 and a GQA group of at most 4 (at most 2 on a paged cache): the vector kernel of
+//              mfa_decode.hip (every K/V byte once, G heads in registers; 73-78 % of HBM peak);
 //   kKvPacked  seqlen_q > 1, or a larger group: the G * seqlen_q query rows of a KV head packed into 32-row MFMA
 //              tiles, keys split over workgroups (MQ instances of the prefill kernel);
 //   kKvPrefill everything else (long query blocks, head dims without a packed instance): the prefill kernel per query
@@ -202,7 +202,10 @@ static int kvcache_route(const mfa_forward_params* p) {
     const int g = p->kv_heads > 0 ? p->heads / p->kv_heads : 1;
     const bool has_packed = p->head_dim == 64 || p->head_dim == 128 || p->head_dim == 256;
     const int64_t rows = static_cast<int64_t>(p->seqlen_q) * g;
-    bool packed = has_packed && rows <= 512 && (p->seqlen_q > 1 || g > 4 || p->use_local_window);
+    // (paged caches: the vector kernel resolves a page per key on the VALU and drops to 4.5-4.9 TB/s for groups of 3-4;
+    //  the packed kernel's row-gather DMA holds 5.3-5.6: profiles/r01d_kvcache_paged_routes.txt)
+    const bool paged_group = p->block_table != nullptr && g >= 3;
+    bool packed = has_packed && rows <= 512 && (p->seqlen_q > 1 || g > 4 || p->use_local_window || paged_group);
     if (env == 0) packed = false;
     if (env == 1 && has_packed) packed = true;
     if (packed) return kKvPacked;

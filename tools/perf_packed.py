@@ -42,7 +42,9 @@ def case(B, Sq, Hq, Hk, Skv, D=128, dtype=torch.bfloat16, splits=0, nbuf=3):
     return us, byts / us / 1e3
 
 
-if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+if __name__ != "__main__":
+    pass
+elif len(sys.argv) > 1 and sys.argv[1] == "sweep":
     for (B, Sq, Hq, Hk, Skv) in ((24, 1, 64, 8, 8192), (24, 8, 24, 8, 8192), (8, 4, 32, 8, 32768), (64, 1, 32, 4, 2048)):
         row = []
         for s in (0, 1, 2, 3, 4, 6, 8, 12, 16, 32):
