@@ -27,6 +27,8 @@ HIP_FLAGS = [
 ]
 if os.environ.get("MFA_ABLATION"):  # developer builds only: timing-only kernel variants selected by $MFA_ABLATE
     HIP_FLAGS.append("-DMFA_ABLATION")
+if os.environ.get("MFA_EXTRA_HIPCC_FLAGS"):  # developer experiments with backend scheduling options
+    HIP_FLAGS += os.environ["MFA_EXTRA_HIPCC_FLAGS"].split()
 
 
 def _run(cmd):
