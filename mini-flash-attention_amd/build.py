@@ -60,7 +60,7 @@ def torch_lib_dir():
 
 def build_hip_lib(force=False):
     os.makedirs(BUILD, exist_ok=True)
-    srcs = ["mfa_prefill.hip", "mfa_decode.hip", "mfa_kvcache.hip", "mfa_capi.cpp"]
+    srcs = ["mfa_prefill.hip", "mfa_prefill64.hip", "mfa_decode.hip", "mfa_kvcache.hip", "mfa_capi.cpp"]
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)

@@ -336,23 +336,30 @@ __global__ __launch_bounds__(64 * kCombineRows) void decode_combine_kernel(const
     const int pos = t % a.seqlen_q;
     const int64_t b = t / a.seqlen_q;
     char* orow = (char*)a.o + 2 * (b * a.o_batch_stride + pos * a.o_row_stride + (int64_t)h * a.o_head_stride);
-    for (int d = d0; d < D; d += 128) { // D is a multiple of 8: pairs never straddle the row end
+    // Every lane walks the column loop (the trip count is wave-uniform); only the loads and the store are
+    // predicated on d < D.  The split weights travel by v_readlane, which ignores EXEC: a ds_bpermute broadcast
+    // under the `d < D` guard returned 0 for weights held by lanes with 2*lane >= D (head dims < 128, splits >= D/2).
+    for (int dd = 0; dd < D; dd += 128) { // D is a multiple of 8: pairs never straddle the row end
+        const int d = dd + d0;
+        const bool col = d < D;
         f32x2 acc = {0.f, 0.f};
         const float* src = a.o_acc + bh * D + d;
         for (int s0 = 0; s0 < S; s0 += CH) {
             f32x2 v[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                if (d == d0 && s0 == 0) v[u] = first[u];
-                else v[u] = s0 + u < S ? *(const f32x2*)(src + (int64_t)(s0 + u) * BH * D) : f32x2{0.f, 0.f};
+                if (dd == 0 && s0 == 0) v[u] = first[u];
+                else v[u] = (col && s0 + u < S) ? *(const f32x2*)(src + (int64_t)(s0 + u) * BH * D) : f32x2{0.f, 0.f};
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int sp = s0 + u; // (weights of splits >= S are 0)
-                acc += __shfl(sp < 64 ? w0 : w1, sp & 63) * v[u];
+                const int sp = s0 + u; // wave-uniform; weights of splits >= S are 0
+                const float w = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sp < 64 ? w0 : w1), sp & 63));
+                acc += w * v[u];
             }
         }
-        *(uint32_t*)(orow + 2 * d) = Elem<T>::pack(acc[0] * invW, acc[1] * invW);
+        if (col) *(uint32_t*)(orow + 2 * d) = Elem<T>::pack(acc[0] * invW, acc[1] * invW);
     }
     if (lane == 0 && a.lse) // (B, H, Sq)
         a.lse[(b * a.heads + h) * a.seqlen_q + pos] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;

@@ -95,6 +95,37 @@ def test_cache_lengths_and_split_equivalence(mfa, capi, Sk, dtype):
             assert ((out.float() - base.float()).abs() <= ulp * base.float().abs() + 1e-5).all()
 
 
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
+@pytest.mark.parametrize("Hq,Hk,Sq", [(4, 1, 1), (8, 1, 1), (8, 1, 3)])
+def test_many_splits_small_head_dims(mfa, capi, D, Hq, Hk, Sq):
+    """Split counts above head_dim/2 (the combine kernel keeps the split weights two per lane; a lane whose
+    column pair lies past head_dim must still hand out its weights).  Auto (0) picks 40+ splits for B=1, few KV
+    heads and a long cache; 33/64/128 are forced.  Both kv-cache routes: the vector kernel (G <= 4, Sq = 1) and
+    the packed-row kernel (G = 8, or Sq > 1); every split count must agree with num_splits=1 and with SDPA."""
+    B, Sk = 1, 8200
+    q, kc, vc = rnd(B, Sq, Hq, D, seed=11), rnd(B, Sk, Hk, D, seed=12), rnd(B, Sk, Hk, D, seed=13)
+    lens = torch.tensor([Sk], dtype=torch.int32, device=DEV)
+    if Sq == 1:
+        ref = sdpa_decode_gpu(q, kc, vc, lens)
+    else:  # bottom-right causal over the cache (flash-attn >= 2.1), as flash_attn_with_kvcache(causal=True)
+        qf = q.float().transpose(1, 2)
+        kf = kc.float().transpose(1, 2).repeat_interleave(Hq // Hk, dim=1)
+        vf = vc.float().transpose(1, 2).repeat_interleave(Hq // Hk, dim=1)
+        sc = qf @ kf.transpose(-1, -2) / D ** 0.5
+        keep = torch.arange(Sk, device=DEV)[None, :] <= (torch.arange(Sq, device=DEV)[:, None] + Sk - Sq)
+        ref = (torch.softmax(sc.masked_fill(~keep, float("-inf")), -1) @ vf).transpose(1, 2)
+    kw = dict(cache_seqlens=lens) if Sq == 1 else dict(cache_seqlens=lens, causal=True)
+    base = mfa.flash_attn_with_kvcache(q, kc, vc, num_splits=1, **kw)
+    assert_close(base, ref, what=f"D{D} G{Hq // Hk} Sq{Sq} splits=1")
+    for splits in (0, 33, 64, 128):
+        out = mfa.flash_attn_with_kvcache(q, kc, vc, num_splits=splits, **kw)
+        assert_close(out, ref, what=f"D{D} G{Hq // Hk} Sq{Sq} splits={splits}")
+        # the vector kernel keeps P in fp32, so its splits agree to summation order; the packed-row (MFMA) kernel rounds
+        # P to bf16 per tile (as the prefill kernel does), so different split boundaries differ by that rounding
+        packed = Sq > 1 or Hq // Hk > 4
+        assert ((out.float() - base.float()).abs() <= 2.0 ** -7 * base.float().abs() + (4e-3 if packed else 1e-5)).all(), f"splits={splits}"
+
+
 @pytest.mark.parametrize("page", [1, 16, 48, 64, 256])
 def test_paged_cache_any_page_size(mfa, capi, page):
     """Paged decode with permuted pages; page sizes below the tile, non-powers of two and 1 are all exact."""

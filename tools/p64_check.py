@@ -1,0 +1,71 @@
+"""Quick parity + timing check of the 64-rows-per-wave prefill kernel against the general kernel and SDPA-fp32 (GPU box).
+  python tools/p64_check.py [quick]"""
+import os, subprocess, sys, time
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
+import mini_flash_attention as mfa
+import torch.nn.functional as F
+from torch.nn.attention import SDPBackend, sdpa_kernel
+
+def ref(q, k, v, causal):
+    g = q.size(2) // k.size(2)
+    qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
+    if g > 1:
+        kf, vf = kf.repeat_interleave(g, 1), vf.repeat_interleave(g, 1)
+    with sdpa_kernel(SDPBackend.MATH):
+        return F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2)
+
+torch.manual_seed(0)
+bad = 0
+shapes = [(1, 64, 64, 1, 1), (1, 256, 256, 2, 2), (2, 512, 512, 4, 2), (1, 1024, 1024, 2, 2), (1, 200, 200, 2, 1), (1, 300, 333, 3, 3),
+          (2, 1, 77, 2, 2), (1, 1000, 1000, 2, 2), (1, 2048, 2048, 1, 1), (1, 257, 511, 2, 2), (3, 129, 64, 2, 2)]
+for dt in (torch.float16, torch.bfloat16):
+    for (B, Sq, Sk, H, Hk) in shapes:
+        for causal in (False, True):
+            if causal and Sq != Sk:
+                continue
+            q = torch.randn(B, Sq, H, 128, device="cuda").to(dt)
+            k = torch.randn(B, Sk, Hk, 128, device="cuda").to(dt)
+            v = torch.randn(B, Sk, Hk, 128, device="cuda").to(dt)
+            o = mfa.flash_attn_func(q, k, v, causal=causal)
+            torch.cuda.synchronize()
+            r = ref(q, k, v, causal)
+            err = (o.float() - r).abs()
+            tol = 1e-3 + (1e-3 + (2 ** -11 if dt == torch.float16 else 2 ** -8)) * r.abs() + (3e-3 if dt == torch.bfloat16 else 0)
+            ok = bool((err <= tol).all()) and bool(torch.isfinite(o).all())
+            bad += not ok
+            print(f"{str(dt)[6:]:9s} B{B} Sq{Sq} Sk{Sk} H{H}/{Hk} causal={int(causal)}: max {err.max().item():.2e} mean {err.mean().item():.2e} {'ok' if ok else 'FAIL'}", flush=True)
+print("FAILURES:", bad, flush=True)
+if bad:
+    sys.exit(1)
+# forced reference-max growth: keys whose scores ramp up tile after tile (exercises the hand-over to the textbook update)
+q = torch.randn(1, 512, 2, 128, device="cuda").half()
+k = torch.randn(1, 512, 2, 128, device="cuda").half()
+v = torch.randn(1, 512, 2, 128, device="cuda").half()
+k = k + (torch.arange(512, device="cuda").view(1, 512, 1, 1) / 16.0).half() * q[:, :1].mean(dim=1, keepdim=True).sign()
+for causal in (False, True):
+    o = mfa.flash_attn_func(q, k, v, causal=causal)
+    r = ref(q, k, v, causal)
+    err = (o.float() - r).abs()
+    print(f"ramp causal={int(causal)}: max {err.max().item():.2e} finite={bool(torch.isfinite(o).all())}", flush=True)
+    if not (err.max().item() < 5e-3):
+        sys.exit(2)
+
+def bench(fn, n=20, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+if len(sys.argv) > 1 and sys.argv[1] == "noperf":
+    sys.exit(0)
+B, H, D = 48, 24, 128
+for S in (1024, 2048, 4096):
+    q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3))
+    for causal in (True, False):
+        ms = bench(lambda: mfa.flash_attn_func(q, k, v, causal=causal), n=20 if S < 4096 else 10)
+        fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+        print(f"S{S} causal={int(causal)}: {ms:.3f} ms {fl / ms / 1e9:.0f} TFLOP/s", flush=True)

@@ -1,0 +1,31 @@
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
+import mini_flash_attention as mfa
+import torch.nn.functional as F
+from torch.nn.attention import SDPBackend, sdpa_kernel
+def ref(q, k, v, causal):
+    qf, kf, vf = (t.float().transpose(1, 2) for t in (q, k, v))
+    with sdpa_kernel(SDPBackend.MATH):
+        return F.scaled_dot_product_attention(qf, kf, vf, is_causal=causal).transpose(1, 2)
+torch.manual_seed(0)
+S = 512
+def run(name, q, k, v, causal=False):
+    o = mfa.flash_attn_func(q, k, v, causal=causal)
+    r = ref(q, k, v, causal)
+    err = (o.float() - r).abs()[0]          # (S, H, D)
+    per = err.amax(dim=(1, 2)).view(-1, 32).amax(dim=1)   # per 32-row block
+    print(name, "max", f"{err.max().item():.2e}", "per 32-row block:", " ".join(f"{x:.1e}" for x in per.tolist()), flush=True)
+q = torch.randn(1, S, 1, 128, device="cuda").half()
+k = torch.randn(1, S, 1, 128, device="cuda").half()
+v = torch.randn(1, S, 1, 128, device="cuda").half()
+run("plain", q, k, v)
+# spike: keys of ONE tile t get a big boost along q-mean direction for all rows
+d = torch.ones(128, device="cuda").half()
+qq = q.clone(); qq[..., :] = (q.float() * 0.2 + 1.0).half()      # all rows have positive projection on d
+for t in (1, 2, 3, 4, 5, 6, 7):
+    kk = k.clone(); kk[0, 64 * t: 64 * t + 64] += 1.5 * d
+    run(f"spike tile {t}", qq, kk, v)
+kk = k.clone(); kk[0] += (torch.arange(S, device="cuda").view(S, 1, 1) / 40.0).half() * d
+run("ramp", qq, kk, v)
+run("ramp causal", qq, kk, v, True)

@@ -1,0 +1,20 @@
+import os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
+import mini_flash_attention as mfa
+def bench(fn, n=20, w=5):
+    for _ in range(w): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+B, H, D = 48, 24, 128
+for rounds in range(2):
+  for dt in (torch.float16, torch.bfloat16):
+    for S, causal in ((1024, True), (2048, False), (4096, False)):
+        q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=dt) for _ in range(3))
+        ms = bench(lambda: mfa.flash_attn_func(q, k, v, causal=causal), n=30 if S < 4096 else 10)
+        fl = 4.0 * B * H * S * S * D * (0.5 if causal else 1.0)
+        print(f"{str(dt)[6:]:9s} S{S} causal={int(causal)}: {ms:.3f} ms {fl / ms / 1e9:.0f} TFLOP/s", flush=True)
