@@ -1,0 +1,38 @@
+"""Where a workgroup of prefill64_kernel spends its time: shader-clock stamps of wave 0 of every workgroup
+(developer aid; MFA_P64_DEBUG=2).   python tools/p64_timeline.py [S] [causal 0/1]"""
+import os, sys
+import torch
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+causal = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
+B, H, D = 48, 24, 128
+nwg = 8 * ((B * H + 7) // 8 // 4 + 1) * 4 * ((S + 255) // 256) + 64
+dbg = torch.zeros(nwg * 8, device="cuda", dtype=torch.int64)
+os.environ["MFA_P64_DBGPTR"] = str(dbg.data_ptr())
+os.environ["MFA_P64_DEBUG"] = str(2 | (int(sys.argv[3]) if len(sys.argv) > 3 else 0))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
+import mini_flash_attention as mfa
+q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3))
+for _ in range(5):
+    mfa.flash_attn_func(q, k, v, causal=causal)
+dbg.zero_()
+mfa.flash_attn_func(q, k, v, causal=causal)
+torch.cuda.synchronize()
+d = dbg.view(-1, 8).cpu()
+d = d[d[:, 0] != 0]
+nt = (d[:, 7] >> 32).float(); ntw = (d[:, 7] & 0xffffffff).float()
+t0 = d[:, 0].min().item()
+names = ["entry->ready (Q + first tiles)", "ready->init done", "init->first tiles done (X0, softmax, X1)", "loop: first steady block", "loop total",
+         "epilogue"]
+seg = [(0, 1), (1, 2), (2, 3), (3, 4), (3, 5), (5, 6)]
+print(f"S={S} causal={causal}: {len(d)} workgroups, kernel span {(d[:, 6].max().item() - t0)} cycles (100 MHz? see below)")
+for ntv in sorted(set(nt.tolist())):
+    m = nt == ntv
+    row = [f"nt={int(ntv):3d} n={int(m.sum()):5d}"]
+    for (a, b), nm in zip(seg, names):
+        x = (d[m, b] - d[m, a]).float()
+        x = x[(d[m, b] != 0) & (d[m, a] != 0)]
+        row.append(f"{x.mean().item() if len(x) else float('nan'):9.0f}")
+    tot = (d[m, 6] - d[m, 0]).float()
+    row.append(f"total {tot.mean().item():9.0f}")
+    print(" ".join(row))
+print("columns:", " | ".join(names))
