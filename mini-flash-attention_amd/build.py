@@ -47,7 +47,7 @@ def _stale(out, deps):
 
 
 def _headers():
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hs.append(os.path.join(ROOT, "include", "mfa.h"))
     hs.append(os.path.abspath(__file__))
     return hs

@@ -15,16 +15,27 @@ Register map (one wave per SIMD, 512 registers: v0..v255 + a0..a255).  Reserved:
 numbers below are RELATIVE to VB / AB.  hipcc allocates from register 0 upwards and keeps the low ones for its own values
 (lane ids, the booleans it parks in VGPRs between blocks, ...):
     v[0:127]    S blocks: tile parity p, chain c: v[(2p+c)*32 + 16*kb + i]   (raw scores, then P packed in place)
-    v[128:143]  V^T fragment ring (4 x 4)          v[144:151] K read addresses (per k-step)
-    v[152:155]  V read addresses (per d & 3)        v[156:159] DMA lane constants k_go, k_gmax, v_go, v_gmax
-    v[160:161]  l0, l1      v[162:163]  lt0, lt1    v[164:165] DMA address temporaries
+    v[128:143]  V^T fragment ring (4 x 4)          v[144:151] K read addresses of ring slot 0 (per k-step)
+    v[152:155]  V read addresses of ring slot 0 (per d & 3)           v[156:157] DMA lane offsets k_go, v_go
+    v[158:159], v[164:165]  DMA lane offsets of the Q staging, by piece & 3
+    v[160:161]  l0, l1      v[162:163]  lt0, lt1 (row sums of the tile in flight)
     v[166:167]  row + hi of chain 0 / 1 (mask bound; 0x3fffffff without a right bound)      v168  4*h
     v[170:171]  -m*c of chain 0 / 1 (addend of the softmax fma)      v[172:173]  m0, m1 (max of the raw scores)
     v[174:179]  temporaries
     a[0:127]    O blocks: chain c, column block d: a[(4c+d)*16]
     a[128:191]  Q fragments: chain c, k-step ks: a[128 + (8c+ks)*4]
     a[192:207]  K fragment ring (4 x 4)
-    s84..s99    scalar temporaries (clobbered)
+    s84, s85    scalar temporaries (clobbered)
+
+LDS: K ring (3 tiles of 16 KiB) then V ring (3 tiles); tile t of either lives in slot t % 3.  The read-address registers
+always hold slot 0; the steady-state loop is unrolled over the six (slot, S-buffer parity) combinations and selects slots
+through the instructions' immediate offsets, the other blocks take the slot's byte offset as a scalar operand.
+
+K/V tiles arrive by LDS-DMA through buffer descriptors (buffer_load_dwordx4 ... lds): lane offset k_go / v_go (row
+4*wave + lane/16 of a 16-row piece and the 16-byte chunk the swizzled image wants at this lane's position), scalar offset
+= the piece's first row.  The descriptors end at the last row the workgroup needs, so a piece past the end (ragged last
+tile, or a tile nobody will read) writes zeros and moves no data.  %[koff] / %[voff] are running: every block that stages a
+tile advances them by the tile's 64 rows, and every wave stages K(j+2) and V(j+1) in iteration j, in that order.
 
 Softmax of one element, in place:  x = fma(x, c, -m*c);  x = exp2(x)   with c = softmax_scale*log2(e) in fp32, as the
 reference scales (prefill.cuh:452-483).  Q is NOT pre-multiplied by c: rounding c*q to 16 bits costs 2^-12 (fp16) / 2^-9
@@ -32,24 +43,32 @@ reference scales (prefill.cuh:452-483).  Q is NOT pre-multiplied by c: rounding 
 O off by 2e-2 on fp16 inputs scaled by 6).  m moves only in the textbook blocks (first tile, or a tile whose row sums of P
 exceed LIMIT): between them P may exceed 1 by up to LIMIT.
 
+One wave issues one instruction per 4 cycles (v_exp_f32: 8; an MFMA holds the issue port for 8 of its 32): a gap between
+two MFMAs hides at most five other instructions, one of them a v_exp_f32.  The steady-state stream is written against that
+budget: per gap one softmax element (fma, exp, row-sum add, every other gap a pack) and on average 1.4 others.
+
 Blocks (P = parity of a tile's S buffer, C = chain); scalar operands are named in each block's _OPS macro:
-    P64_INIT            operands -> home registers; O, l := 0           (a wave without rows: it only stages tiles)
-    P64_INIT_X0         the same + phase X of tile 0 into buffer 0
+    P64_SETUP           lane constants (LDS read addresses, DMA lane offsets, 4h) -> home registers, once per workgroup
+    P64_DMA_Q           the wave's Q rows of a work item: global memory -> its LDS Q buffer (asynchronous: vmcnt)
+    P64_Q_LDS           Q fragments: LDS Q buffer -> home registers
+    P64_X0              a new work item: phase X of tile 0 into buffer 0; O, l := 0 and the mask bounds in its gaps
     P64_FIRST0          the textbook softmax of tile 0 (sets m)
     P64_X1_FIRST0       phase X of tile 1 into buffer 1 with the textbook softmax of tile 0 in its gaps
-    P64_STEADY          the steady-state loop: pairs of iterations (odd tile j, even tile j+1), each
-                        [barrier] phase Y (P.V of tile j-1) | phase X (QK^T of tile j+1), the softmax of tile j and the
-                        LDS reads / DMA pieces in the gaps between the MFMAs, fragment reads handed over between phases;
-                        leaves when j >= jend (status 0) or when a tile's row sums fail the test (status 1)
-    P64_X{P}_SM         phase X alone: scores of the tile k_rd points at into buffer P, softmax steps 32..63 of buffer P^1
-    P64_Y{P}[_SM]       phase Y alone: O += V.P, P in buffer P, V tile v_rd points at [softmax steps 0..31 of buffer P^1]
+    P64_STEADY          the steady-state loop over tiles j = %[j] .. %[jend]-1, entered at any j (%[entry] = j % 6): per
+                        iteration [barrier] phase Y (P.V of tile j-1) | phase X (QK^T of tile j+1), the softmax of tile j,
+                        the LDS reads and the DMA pieces of K(j+2), V(j+1) in the gaps between the MFMAs, fragment reads
+                        handed over between phases; leaves at jend (status 0) or when a tile's row sums fail the test
+                        (status 1, tile j's phases done, its sums not yet accepted)
+    P64_X{P}_SM         phase X alone: scores of the K tile in slot %[kslot] into buffer P, softmax steps 32..63 of buffer P^1
+    P64_Y{P}[_SM]       phase Y alone: O += V.P, P in buffer P, V tile in slot %[vslot] [softmax steps 0..31 of buffer P^1]
     P64_SM2_{P}         softmax steps 32..63 of buffer P with nothing to hide under
     P64_MASK{P}         key > row + hi or key >= sk -> -inf on both chains of buffer P
     P64_CHECK           test of the two tile sums; passing chains: l += lt; status bit c = chain c failed
-    P64_REDO{P}{C}      chain C of the tile in buffer P the textbook way: scores again from the K tile in the ring, mask,
+    P64_REDO{P}{C}      chain C of the tile in buffer P the textbook way: scores again from the K tile in slot %[kslot], mask,
                         new max, rescale of O and l, P
     P64_DMA_K / _V      the four 1-KiB pieces of one K / V tile as a burst
-    P64_FINAL           home registers -> operands (O, l, m)
+    P64_EPILOGUE        O / l -> global memory: 1/l, pack, rows through this wave's LDS staging area, buffer stores
+    P64_FINAL           home registers -> operands (l, m: for the LSE)
 The phases outside the loop read their own first fragments (no hand-over), so any sequence of them is valid.
 """
 import os
@@ -82,7 +101,8 @@ def VRD(d):
     return 152 + d
 
 
-V_KGO, V_KGMAX, V_VGO, V_VGMAX = 156, 157, 158, 159
+V_KGO, V_VGO = 156, 157
+QGO = (158, 159, 164, 165)  # Q staging lane offsets, by piece & 3
 
 
 def L(c):
@@ -91,9 +111,6 @@ def L(c):
 
 def LT(c):
     return 162 + c
-
-
-VT = (164, 165)
 
 
 def QHI(c):
@@ -127,9 +144,7 @@ def KFR(k):
     return 192 + 4 * k
 
 
-# scalar temporaries
-(S_KOFF, S_VOFF, S_DSTK, S_DSTV, S_KDELTA, S_VDELTA, S_K16, S_V16, S_K64, S_V64, S_KNEXT, S_VNEXT, S_T0, S_T1, S_T2,
- S_T3) = range(84, 100)
+S_T0 = 84  # scalar temporary
 
 
 def vr(lo, n=1):
@@ -147,7 +162,6 @@ class Stream:
         self.out = []
         self.mf = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
-        self.dma_t = 0
         self.lds_log = []
         self.ablate = set()  # developer timing builds: "dma", "sm", "lds" leave that part of the steady loop out
 
@@ -161,77 +175,77 @@ class Stream:
         self.e("s_nop 7")
 
     # ---- softmax of one tile as 64 element steps u (u & 1: chain, u >> 1: element 16*kb + i): fma + exp in place now,
-    # the row-sum add one element later, the pack of a finished pair (in place, word i/2) right behind its second add
+    # the row-sum add one element later (the first add of a tile writes lt = x0 + x1), the pack of a finished pair (in
+    # place, word i/2) right behind its second add
     def sm_step(self, P, u):
-        if "sm" in self.ablate:
+        if "sm" in self.ablate or ("smx" in self.ablate and u >= 32) or ("smy" in self.ablate and u < 32):
             return
         ch, e = u & 1, u >> 1
-        sb = S_BASE(P, ch)
-        self.e(f"v_fma_f32 {vr(sb + e)}, {vr(sb + e)}, %[c], {vr(MC(ch))}")
-        self.e(f"v_exp_f32 {vr(sb + e)}, {vr(sb + e)}")
+
+        x = vr(S_BASE(P, ch) + e)
+        self.e(f"v_fma_f32 {x}, {x}, %[c], {vr(MC(ch))}")  # (issuing the fma a step ahead of its exp: measured, no gain)
+        self.e(f"v_exp_f32 {x}, {x}")
         if u >= 2:
-            e2 = e - 1
+            self.sm_sum(P, ch, e - 1)
+
+    def sm_sum(self, P, ch, e2):
+        sb = S_BASE(P, ch)
+        if e2 == 1:
+            self.e(f"v_add_f32 {vr(LT(ch))}, {vr(sb)}, {vr(sb + 1)}")
+        elif e2 > 1:
             self.e(f"v_add_f32 {vr(LT(ch))}, {vr(LT(ch))}, {vr(sb + e2)}")
-            if e2 & 1:
-                kb2, i2 = e2 >> 4, e2 & 15
-                self.e(f"{self.cvt} {vr(sb + 16 * kb2 + (i2 >> 1))}, {vr(sb + e2 - 1)}, {vr(sb + e2)}")
+        if e2 & 1 and "cvt" not in self.ablate:
+            kb2, i2 = e2 >> 4, e2 & 15
+            self.e(f"{self.cvt} {vr(sb + 16 * kb2 + (i2 >> 1))}, {vr(sb + e2 - 1)}, {vr(sb + e2)}")
 
     def sm_tail(self, P):
         if "sm" in self.ablate:
             return
         for ch in range(2):
-            sb = S_BASE(P, ch)
-            self.e(f"v_add_f32 {vr(LT(ch))}, {vr(LT(ch))}, {vr(sb + 31)}")
-            self.e(f"{self.cvt} {vr(sb + 16 + 7)}, {vr(sb + 30)}, {vr(sb + 31)}")
+            self.sm_sum(P, ch, 31)
 
     # LDS reads are logged in issue order (tag = (kind, phase sequence number, fragment)), so that a wait for a fragment
-    # can be written as "all but the reads issued after it": lgkmcnt(N), N = reads younger than the fragment's last one
-    def k_read(self, f, seq=0):
+    # can be written as "all but the reads issued after it": lgkmcnt(N), N = reads younger than the fragment's last one.
+    # slot: ring slot as an immediate (the address registers hold slot 0)
+    def k_read(self, f, seq=0, slot=0):
         kb, ks = f >> 3, f & 7
         self.lds_log.append(("K", seq, f))
         if "lds" not in self.ablate:
-            self.e(f"ds_read_b128 {ar(KFR(f & PF), 4)}, {vr(KRD(ks))} offset:{kb * 32 * 256}")
+            self.e(f"ds_read_b128 {ar(KFR(f & PF), 4)}, {vr(KRD(ks))} offset:{slot * TILE + kb * 32 * 256}")
 
-    def v_read_half(self, f, half, seq=0):
+    def v_read_half(self, f, half, seq=0, slot=0):
         s16, d = f >> 2, f & 3
         self.lds_log.append(("V", seq, f))
         if "lds" not in self.ablate:
-            self.e(f"ds_read_b64_tr_b16 {vr(VFR(f & PF) + 2 * half, 2)}, {vr(VRD(d))} offset:{s16 * 16 * 256 + half * 8 * 256}")
+            self.e(f"ds_read_b64_tr_b16 {vr(VFR(f & PF) + 2 * half, 2)}, {vr(VRD(d))} "
+                   f"offset:{slot * TILE + s16 * 16 * 256 + half * 8 * 256}")
 
-    def v_read(self, f, seq=0):
-        self.v_read_half(f, 0, seq)
-        self.v_read_half(f, 1, seq)
+    def v_read(self, f, seq=0, slot=0):
+        self.v_read_half(f, 0, seq, slot)
+        self.v_read_half(f, 1, seq, slot)
 
     def wait_frag(self, kind, seq, f, pad=False):
         """Everything up to fragment (kind, seq, f) has landed.  An MFMA must not follow the wait directly: a wait that
         really waited is passed a few cycles before the first dword is readable by the matrix core (measured: the first
         consumer lost that dword).  The streams put a slot's fillers between the two; bare phases pad with s_nop."""
         last = max(i for i, t in enumerate(self.lds_log) if t == (kind, seq, f))
-        if "lds" in self.ablate:
+        if "lds" in self.ablate or "wait" in self.ablate:
             return
         self.e(f"s_waitcnt lgkmcnt({len(self.lds_log) - 1 - last})")
         if pad:
             self.e("s_nop 3")
 
-    def dma_piece(self, pc):
-        if "dma" in self.ablate:
-            return
-        vt = VT[self.dma_t & 1]
-        self.dma_t += 1
-        if pc < NI:
-            go, gmax, off, dst, step, base, p = V_KGO, V_KGMAX, S_KOFF, S_DSTK, S_K16, "%[kbase]", pc
-        else:
-            go, gmax, off, dst, step, base, p = V_VGO, V_VGMAX, S_VOFF, S_DSTV, S_V16, "%[vbase]", pc - NI
-        self.e(f"v_add_u32 {vr(vt)}, s{off}, {vr(go)}")
-        self.e(f"v_min_u32 {vr(vt)}, {vr(vt)}, {vr(gmax)}")
-        self.e(f"s_add_u32 m0, s{dst}, {p * NW * 1024}")
-        self.e(f"s_add_u32 s{off}, s{off}, s{step}")  # (also the wait state between the M0 write and its use)
-        self.e(f"global_load_lds_dwordx4 {vr(vt)}, {base}")
-
-    def next_slot(self, dst, src):
-        self.e(f"s_add_u32 s{dst}, {src}, {TILE}")
-        self.e(f"s_cmp_eq_u32 s{dst}, {RING * TILE}")
-        self.e(f"s_cselect_b32 s{dst}, 0, s{dst}")
+    def filler(self):
+        for tag in self.ablate:
+            if tag.startswith("fill"):
+                for n in range(int(tag[4:])):
+                    k = getattr(self, "_fk", 0)
+                    self._fk = (k + 1) % 6
+                    self.e(f"v_add_f32 {vr(TMP(0, 0) + k)}, {vr(TMP(0, 0) + k)}, {vr(MC(0))}")
+            if tag.startswith("fexp"):
+                k = getattr(self, "_fk", 0)
+                self._fk = (k + 1) % 6
+                self.e(f"v_exp_f32 {vr(TMP(0, 0) + k)}, {vr(MC(0))}")
 
     def mfma_x(self, PN, t):
         ch, f = t & 1, t >> 1
@@ -248,121 +262,131 @@ class Stream:
         self.e(f"{self.mf} {ar(o, 16)}, {vr(VFR(f & PF), 4)}, {vr(S_BASE(PP, ch) + 16 * kb + 4 * sh, 4)}, {ar(o, 16)}")
 
     # ---- one iteration of the steady-state loop
-    def iteration(self, P, fail_label, seq):
-        """tile j = %[j] (parity P): P(j-1) and the destination of S(j+1) are in the buffer of parity P^1; seq: sequence
-        number of its phase Y (the wait for that phase's first V fragment has been done by whoever came before)"""
-        self.e(f"; ---- iteration, tile parity {P}")
-        self.e("s_waitcnt vmcnt(0)")
-        self.e("s_barrier")
-        # ring slots: K(j+2) goes behind the slot K(j+1) is read from, V(j+1) two behind the slot V(j-1) is read from
-        self.next_slot(S_KNEXT, "%[kslot]")
-        self.e(f"s_add_u32 s{S_DSTK}, %[dst0], s{S_KNEXT}")
-        self.e(f"s_sub_u32 s{S_KDELTA}, s{S_KNEXT}, %[kslot]")
-        self.e(f"s_sub_u32 s{S_T0}, %[vslot], {TILE}")
-        self.e("s_cmp_eq_u32 %[vslot], 0")
-        self.e(f"s_cselect_b32 s{S_T0}, {(RING - 1) * TILE}, s{S_T0}")
-        self.e(f"s_add_u32 s{S_DSTV}, %[dst0], s{S_T0}")
-        self.e(f"s_add_u32 s{S_DSTV}, s{S_DSTV}, {V_RING}")
-        self.next_slot(S_VNEXT, "%[vslot]")
-        self.e(f"s_sub_u32 s{S_VDELTA}, s{S_VNEXT}, %[vslot]")
-        self.e(f"s_add_u32 s{S_T0}, %[j], 2")
-        self.e(f"s_mul_i32 s{S_KOFF}, s{S_T0}, s{S_K64}")
-        self.e(f"s_add_u32 s{S_T0}, %[j], 1")
-        self.e(f"s_mul_i32 s{S_VOFF}, s{S_T0}, s{S_V64}")
+    def iteration(self, i):
+        """tile j = %[j], j % 6 == i: S(j) in buffer P = i & 1; P(j-1) and the destination of S(j+1) in buffer P^1; the
+        V tile of phase Y in slot (i-1) % 3, the K tile of phase X in slot (i+1) % 3; K(j+2) goes to slot (i+2) % 3, V(j+1)
+        to slot (i+1) % 3.  On entry the first PF V fragments are on their way and fragment 0 has landed."""
+        P = i & 1
+        vs, ks_, vs_next = (i - 1) % 3, (i + 1) % 3, i % 3
+        self.lds_log = [("V", 0, f) for f in range(PF) for _ in range(2)]
+        self.e(f"; ---- iteration, tile j %% 6 == {i}")
+        self.e(f"1{i}:")
+        if "bar" not in self.ablate:
+            self.e("s_waitcnt vmcnt(0)")
+            self.e("s_barrier")
         # ---- phase Y: O^T += V^T.P^T of tile j-1 (slot t: chain t & 1, V fragment t >> 1 = 4*s16 + d).  The wait for a
         # fragment sits behind the MFMA of the slot before its first use (that slot's fillers separate it from the
         # consumer).  Fragment f + PF is read into the ring entry fragment f - 1 has left: its low half behind the first
-        # MFMA of fragment f, its high half behind the second.
+        # MFMA of fragment f, its high half behind the second.  Eight DMA pieces, behind every fourth MFMA.
         for t in range(32):
             ch, f = t & 1, t >> 1
             self.mfma_y(P ^ 1, t)
+            self.filler()
             if ch == 1:
                 if f < 15:
-                    self.wait_frag("V", seq, f + 1)
+                    self.wait_frag("V", 0, f + 1)
                 else:
-                    self.wait_frag("K", seq + 1, 0)
+                    self.wait_frag("K", 1, 0)
+            dma = ch == 1 and f % 2 == 0 and "dma" not in self.ablate
+            if dma:
+                pc = f // 2
+                if pc < NI:
+                    self.e(f"s_add_u32 m0, %[dst0], {((i + 2) % 3) * TILE + pc * NW * 1024}")
+                else:
+                    self.e(f"s_add_u32 m0, %[dst0], {V_RING + ((i + 1) % 3) * TILE + (pc - NI) * NW * 1024}")
+            if t == 0 and "sm" not in self.ablate:  # the sums of tile j-1 (accepted at the end of the last iteration)
+                for c2 in range(2):
+                    self.e(f"v_add_f32 {vr(L(c2))}, {vr(L(c2))}, {vr(LT(c2))}")
             self.sm_step(P, t)
             if f + PF <= 15:
-                self.v_read_half(f + PF, ch, seq)
+                self.v_read_half(f + PF, ch, 0, vs)
             elif ch == 0:
-                self.k_read(f + PF - 16, seq + 1)
-            if ch == 1 and f >= 12:  # every V read through v_rd[f-12] is out: on to the next V tile
-                self.e(f"v_add_u32 {vr(VRD(f - 12))}, s{S_VDELTA}, {vr(VRD(f - 12))}")
-            if ch == 1 and f % 2 == 0:  # eight DMA pieces, behind every fourth MFMA
-                self.dma_piece(f // 2)
+                self.k_read(f + PF - 16, 1, ks_)
+            if dma:
+                if pc < NI:
+                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, %[ksrd], %[koff] offen lds")
+                    self.e("s_add_u32 %[koff], %[koff], %[k16]")
+                else:
+                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, %[vsrd], %[voff] offen lds")
+                    self.e("s_add_u32 %[voff], %[voff], %[v16]")
         # ---- phase X: S^T = K.Q^T of tile j+1 into the buffer P^1 (slot t: chain t & 1, K fragment t >> 1 = 8*kb + ks)
         for t in range(32):
             ch, f = t & 1, t >> 1
             self.mfma_x(P ^ 1, t)
+            self.filler()
             if ch == 1:
                 if f < 15:
-                    self.wait_frag("K", seq + 1, f + 1)
+                    self.wait_frag("K", 1, f + 1)
                 else:
-                    self.wait_frag("V", seq + 2, 0)
+                    self.wait_frag("V", 2, 0)
             self.sm_step(P, 32 + t)
             if f + PF <= 15:
                 if ch == 0:
-                    self.k_read(f + PF, seq + 1)
+                    self.k_read(f + PF, 1, ks_)
             else:
-                self.v_read_half(f + PF - 16, ch, seq + 2)
-            if ch == 1 and f >= 8:  # every K read through k_rd[f-8] is out: on to the next K tile
-                self.e(f"v_add_u32 {vr(KRD(f - 8))}, s{S_KDELTA}, {vr(KRD(f - 8))}")
+                self.v_read_half(f + PF - 16, ch, 2, vs_next)
+            if t == 30:  # (no scalar instruction behind this one writes SCC before the loop test)
+                self.e("s_add_u32 %[j], %[j], 1")
+                self.e("s_cmp_lt_i32 %[j], %[jend]")
         self.sm_tail(P)
-        # ring state after the phases; then the test of the two tile sums: !(lt <= limit), NaN included
-        self.e(f"s_mov_b32 %[kslot], s{S_KNEXT}")
-        self.e(f"s_mov_b32 %[vslot], s{S_VNEXT}")
-        self.e(f"v_cmp_nge_f32 vcc, 0x{LIMIT:x}, {vr(LT(0))}")
-        self.e("s_nop 1")
-        self.e(f"s_mov_b64 s[{S_T0}:{S_T1}], vcc")
-        self.e(f"v_cmp_nge_f32 vcc, 0x{LIMIT:x}, {vr(LT(1))}")
-        self.e("s_nop 1")
-        self.e(f"s_or_b64 s[{S_T0}:{S_T1}], s[{S_T0}:{S_T1}], vcc")
-        self.e(f"s_cmp_lg_u64 s[{S_T0}:{S_T1}], 0")
-        self.e(f"s_cbranch_scc1 {fail_label}")
-        for ch in range(2):
-            self.e(f"v_add_f32 {vr(L(ch))}, {vr(L(ch))}, {vr(LT(ch))}")
-        for ch in range(2):
-            self.e(f"v_mov_b32 {vr(LT(ch))}, 0")
-        self.e("s_add_u32 %[j], %[j], 1")
+        assert self.lds_log[-2 * PF:] == [("V", 2, f) for f in range(PF) for _ in range(2)]
+        # the test of the tile sums: !(lt0 + lt1 <= limit), NaN included (which chain: P64_CHECK)
+        if not self.ablate & {"sm", "smx", "smy"}:
+            self.e(f"v_add_f32 {vr(TMP(0, 0))}, {vr(LT(0))}, {vr(LT(1))}")
+            self.e(f"v_cmp_nge_f32 vcc, 0x{LIMIT:x}, {vr(TMP(0, 0))}")
+            self.e("s_cbranch_vccnz 7f")
+        self.e("s_cbranch_scc0 8f")
 
     def steady(self):
         self.e("; steady-state tile loop of prefill64_kernel (generated by tools/gen_p64_stream.py)")
         self.e("s_mov_b32 %[status], 0")
         self.e("s_cmp_ge_i32 %[j], %[jend]")
         self.e("s_cbranch_scc1 9f")
-        self.e(f"s_lshl_b32 s{S_K64}, %[ksb], 6")
-        self.e(f"s_lshl_b32 s{S_K16}, %[ksb], 4")
-        self.e(f"s_lshl_b32 s{S_V64}, %[vsb], 6")
-        self.e(f"s_lshl_b32 s{S_V16}, %[vsb], 4")
         self.pads()
-        for f in range(PF):  # the first V fragments of phase Y of the first iteration
-            self.v_read(f, 0)
-        self.wait_frag("V", 0, 0, pad=True)
-        self.e("1:")
-        self.iteration(1, "7f", 0)
-        self.iteration(0, "7f", 2)
-        # (the loop closes here: the reads still in flight are the first V fragments of sequence 4 == 0 of the next trip)
-        assert self.lds_log[-6:] == [("V", 4, 0)] * 2 + [("V", 4, 1)] * 2 + [("V", 4, 2)] * 2
-        self.e("s_cmp_lt_i32 %[j], %[jend]")
-        self.e("s_cbranch_scc1 1b")
-        self.e("s_branch 9f")
-        self.e("7:")
+        for i in range(1, 6):
+            self.e(f"s_cmp_eq_u32 %[entry], {i}")
+            self.e(f"s_cbranch_scc1 2{i}f")
+        for i in range(6):  # entries: the first V fragments of phase Y; no sums pending
+            self.e(f"2{i}:")
+            self.lds_log = []
+            for f in range(PF):
+                self.v_read(f, 0, (i - 1) % 3)
+            for c2 in range(2):
+                self.e(f"v_mov_b32 {vr(LT(c2))}, 0")
+            self.wait_frag("V", 0, 0, pad=True)
+            self.e(f"s_branch 1{i}f")
+        for i in range(6):
+            self.iteration(i)
+        self.e("s_branch 10b")
+        self.e("7:")  # tile j's sums failed the test: j was already advanced
+        self.e("s_sub_u32 %[j], %[j], 1")
         self.e("s_mov_b32 %[status], 1")
+        self.e("s_branch 9f")
+        self.e("8:")  # j == jend: the sums of the last tile
+        if "sm" not in self.ablate:
+            for c2 in range(2):
+                self.e(f"v_add_f32 {vr(L(c2))}, {vr(L(c2))}, {vr(LT(c2))}")
         self.e("9:")
         self.e("s_waitcnt lgkmcnt(0)")  # fragments read ahead for an iteration that will not run here
         self.pads()
         return self.out
 
     # ---- the self-contained phases used outside the steady-state loop; `fill`: extra instructions to spread over the
-    # gaps (a list, consumed in order)
-    def phase_x(self, PN, sm, fill=None):
+    # gaps; slot: ring slot as an immediate, or None: byte offset in %[kslot] / %[vslot]
+    def phase_x(self, PN, sm, fill=None, slot=None):
         fill = list(fill or [])
         share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
+        self.lds_log = []
         self.pads()
-        self.next_slot(S_KNEXT, "%[kslot]")
-        self.e(f"s_sub_u32 s{S_KDELTA}, s{S_KNEXT}, %[kslot]")
+        if slot is None:
+            for ks in range(8):
+                self.e(f"v_add_u32 {vr(KRD(ks))}, %[kslot], {vr(KRD(ks))}")
+            slot = 0
+            moved = True
+        else:
+            moved = False
         for f in range(PF):
-            self.k_read(f)
+            self.k_read(f, 0, slot)
         self.wait_frag("K", 0, 0, pad=True)
         for t in range(32):
             ch, f = t & 1, t >> 1
@@ -373,19 +397,20 @@ class Stream:
                 self.sm_step(PN ^ 1, 32 + t)
             self.out += share[t]
             if ch == 0 and f + PF <= 15:
-                self.k_read(f + PF)
-            if ch == 1 and f >= 8:
-                self.e(f"v_add_u32 {vr(KRD(f - 8))}, s{S_KDELTA}, {vr(KRD(f - 8))}")
+                self.k_read(f + PF, 0, slot)
         if sm:
             self.sm_tail(PN ^ 1)
-        self.e(f"s_mov_b32 %[kslot], s{S_KNEXT}")
+        if moved:
+            for ks in range(8):
+                self.e(f"v_subrev_u32 {vr(KRD(ks))}, %[kslot], {vr(KRD(ks))}")
         self.pads()
         return self.out
 
     def phase_y(self, PP, sm):
+        self.lds_log = []
         self.pads()
-        self.next_slot(S_VNEXT, "%[vslot]")
-        self.e(f"s_sub_u32 s{S_VDELTA}, s{S_VNEXT}, %[vslot]")
+        for d in range(4):
+            self.e(f"v_add_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
         for f in range(PF):
             self.v_read(f)
         self.wait_frag("V", 0, 0, pad=True)
@@ -398,9 +423,8 @@ class Stream:
                 self.sm_step(PP ^ 1, t)
             if f + PF <= 15:
                 self.v_read_half(f + PF, ch)
-            if ch == 1 and f >= 12:
-                self.e(f"v_add_u32 {vr(VRD(f - 12))}, s{S_VDELTA}, {vr(VRD(f - 12))}")
-        self.e(f"s_mov_b32 %[vslot], s{S_VNEXT}")
+        for d in range(4):
+            self.e(f"v_subrev_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
         self.pads()
         return self.out
 
@@ -471,7 +495,6 @@ class Stream:
                 b = sb + 16 * kb
                 self.e(f"{self.cvt} {vr(b + i)}, {vr(b + 2 * i)}, {vr(b + 2 * i + 1)}")
         self.e(f"v_add_f32 {vr(L(ch))}, {vr(L(ch))}, {vr(t2)}")
-        self.e(f"v_mov_b32 {vr(LT(ch))}, 0")
         lines, self.out = self.out, out
         return lines
 
@@ -494,19 +517,16 @@ class Stream:
         return self.out
 
     def x_first_block(self):
-        """phase X of tile 1 (buffer 1) with the textbook softmax of tile 0 (buffer 0) in its gaps"""
+        """phase X of tile 1 (slot %[kslot], buffer 1) with the textbook softmax of tile 0 (buffer 0) in its gaps"""
         return self.phase_x(1, False, fill=self.first_lines(0))
 
     def check_block(self):
-        """status bit c = chain c failed the test of its tile sum; passing chains: l += lt, lt = 0"""
+        """status bit c = chain c failed the test of its tile sum; passing chains: l += lt"""
         self.e("s_mov_b32 %[status], 0")
         for ch in range(2):
             self.e(f"v_cmp_nge_f32 vcc, 0x{LIMIT:x}, {vr(LT(ch))}")
-            self.e("s_nop 1")
-            self.e("s_cmp_lg_u64 vcc, 0")
-            self.e(f"s_cbranch_scc1 {ch + 1}f")
+            self.e(f"s_cbranch_vccnz {ch + 1}f")
             self.e(f"v_add_f32 {vr(L(ch))}, {vr(L(ch))}, {vr(LT(ch))}")
-            self.e(f"v_mov_b32 {vr(LT(ch))}, 0")
             self.e(f"s_branch {ch + 3}f")
             self.e(f"{ch + 1}:")
             self.e(f"s_or_b32 %[status], %[status], {1 << ch}")
@@ -514,13 +534,13 @@ class Stream:
         return self.out
 
     def redo_block(self, P, ch):
-        """%[kdelta]: byte offset of the tile's K ring slot relative to the slot k_rd points at"""
+        """%[kslot]: byte offset of the tile's K ring slot"""
         self.pads()
         t2 = TMP(ch, 2)
         for kb in range(2):
             for ks in range(8):
                 sn = S_BASE(P, ch) + 16 * kb
-                self.e(f"v_add_u32 {vr(t2)}, %[kdelta], {vr(KRD(ks))}")
+                self.e(f"v_add_u32 {vr(t2)}, %[kslot], {vr(KRD(ks))}")
                 self.e(f"ds_read_b128 {ar(KFR(0), 4)}, {vr(t2)} offset:{kb * 32 * 256}")
                 self.e("s_waitcnt lgkmcnt(0)")
                 self.e("s_nop 3")
@@ -533,17 +553,64 @@ class Stream:
         return self.out
 
     def dma_block(self, is_v):
-        """%[off]: byte offset of the tile's first row, %[dst]: LDS byte address of this wave's first piece in the slot,
-        %[step]: 16 rows in bytes, %[base]: the K / V base of the (batch, head)"""
-        go, gmax = (V_VGO, V_VGMAX) if is_v else (V_KGO, V_KGMAX)
-        self.e(f"s_mov_b32 s{S_T0}, %[off]")
+        """%[off]: byte offset of the tile's first row (running: left at the next tile's), %[dst]: LDS byte address of this
+        wave's first piece in the slot, %[step]: 16 rows in bytes, %[srd]: the K / V descriptor of the (batch, head)"""
+        go = V_VGO if is_v else V_KGO
         for p in range(NI):
-            vt = VT[p & 1]
-            self.e(f"v_add_u32 {vr(vt)}, s{S_T0}, {vr(go)}")
-            self.e(f"v_min_u32 {vr(vt)}, {vr(vt)}, {vr(gmax)}")
             self.e(f"s_add_u32 m0, %[dst], {p * NW * 1024}")
-            self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[step]")
-            self.e(f"global_load_lds_dwordx4 {vr(vt)}, %[base]")
+            self.e("s_nop 0")
+            self.e(f"buffer_load_dwordx4 {vr(go)}, %[srd], %[off] offen lds")
+            self.e("s_add_u32 %[off], %[off], %[step]")
+        return self.out
+
+    def epilogue_block(self):
+        """O / l of both chains -> global memory as whole rows (reference prefill.cuh:600-612): 1/l (1 for a row without
+        keys), pack, this wave's LDS staging area (32 rows of 272 bytes, one chain at a time), rows back as 16-byte
+        pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped).
+        %[wr] = stage + r*272 + 8h, %[rd] = stage + (lane/16)*272 + 16*(lane%16), %[ovoff] = (first row of the wave +
+        lane/16) * row bytes + 16*(lane%16), %[osb4] = 4 rows in bytes"""
+        T = lambda i: S_BASE(0, 0) + i  # temporaries: the S buffers are free now
+        inv = [T(0), T(1)]
+        self.pads()
+        for ch in range(2):
+            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
+            self.e(f"v_mov_b32 {vr(t0)}, {vr(L(ch))}")
+            self.e(f"v_mov_b32 {vr(t1)}, {vr(L(ch))}")
+        self.e("s_nop 1")
+        for ch in range(2):
+            self.e(f"v_permlane32_swap_b32 {vr(T(2 + 2 * ch))}, {vr(T(3 + 2 * ch))}")
+        self.e("s_nop 1")
+        for ch in range(2):
+            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
+            self.e(f"v_add_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
+            self.e(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
+            self.e(f"v_cmp_lt_f32 vcc, 0, {vr(t0)}")
+            self.e("s_nop 0")
+            self.e(f"v_cndmask_b32 {vr(inv[ch])}, 1.0, {vr(t1)}, vcc")
+        self.e(f"s_mov_b32 s{S_T0}, 0")
+        for ch in range(2):
+            if ch == 1:
+                self.e("s_waitcnt lgkmcnt(0)")
+            n = 0
+            for d in range(4):
+                for g4 in range(4):
+                    x = T(8 + 4 * (n % 8))
+                    n += 1
+                    for i in range(4):
+                        self.e(f"v_accvgpr_read_b32 {vr(x + i)}, {ar(O_BASE(ch, d) + 4 * g4 + i)}")
+                    for i in range(4):
+                        self.e(f"v_mul_f32 {vr(x + i)}, {vr(x + i)}, {vr(inv[ch])}")
+                    self.e(f"{self.cvt} {vr(x)}, {vr(x)}, {vr(x + 1)}")
+                    self.e(f"{self.cvt} {vr(x + 1)}, {vr(x + 2)}, {vr(x + 3)}")
+                    self.e(f"ds_write_b64 %[wr], {vr(x, 2)} offset:{16 * (4 * d + g4)}")
+            self.e("s_waitcnt lgkmcnt(0)")
+            R = lambda it: T(48 + 4 * it)
+            for it in range(8):
+                self.e(f"ds_read_b128 {vr(R(it), 4)}, %[rd] offset:{it * 4 * 272}")
+            for it in range(8):
+                self.e(f"s_waitcnt lgkmcnt({7 - it})")
+                self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen")
+                self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[osb4]")
         return self.out
 
     def init_lines(self):
@@ -551,18 +618,48 @@ class Stream:
         lines += [f"v_mov_b32 {vr(r)}, 0" for r in (L(0), L(1), LT(0), LT(1), M(0), M(1), MC(0), MC(1))]
         return lines
 
-    def init_block(self):
-        self.out += self.init_lines()
-        self.e("s_nop 4")
+    def setup_block(self):
+        self.e("s_nop 0")
         return self.out
 
-    def init_x0_block(self):
-        """phase X of tile 0 into buffer 0, the zeroing of O and l in its gaps"""
-        return self.phase_x(0, False, fill=self.init_lines())
+    def x0_block(self):
+        """a new work item: phase X of its tile 0 (slot %[kslot]) into buffer 0; O, l := 0 and the item's mask bounds
+        (%[qhi0], %[qhi1]) -> home registers in its gaps.  Q is in its home registers (P64_Q_LDS)."""
+        lines = self.init_lines() + [f"v_mov_b32 {vr(QHI(c))}, %[qhi{c}]" for c in range(2)]
+        return self.phase_x(0, False, fill=lines)
+
+    def dma_q_block(self):
+        """the wave's 64 Q rows of a work item -> its LDS Q buffer, as a K-tile-shaped image (16 pieces of 4 rows; row i at
+        256*i, its 16-byte chunks XOR-swizzled by i & 15): whole rows per request, where fragment-shaped loads straight
+        from memory (32 rows x 32 bytes per instruction) cost the texture unit four times the cycles.
+        %[off]: 0 (running), %[dst]: LDS byte address of the buffer, %[step]: 4 rows in bytes, %[srd]: descriptor of the
+        wave's rows (rows >= seqlen_q: zeros)"""
+        for p in range(16):
+            self.e(f"s_add_u32 m0, %[dst], {p * 1024}")
+            self.e("s_nop 0")
+            self.e(f"buffer_load_dwordx4 {vr(QGO[p & 3])}, %[srd], %[off] offen lds")
+            self.e("s_add_u32 %[off], %[off], %[step]")
+        return self.out
+
+    def q_lds_block(self):
+        """Q fragments (B operand of S^T = K.Q^T: row, columns 16*ks + 8h .. +7, as stored; the scale is applied to the
+        fp32 scores) from the wave's LDS Q buffer -> home registers.  The image is K-tile-shaped, so the K read addresses
+        serve: %[qoff] = the buffer's offset from the K ring's slot 0.  Run between two work items (S buffers free)."""
+        T = lambda i: S_BASE(0, 0) + i
+        for ks in range(8):
+            self.e(f"v_add_u32 {vr(T(ks))}, %[qoff], {vr(KRD(ks))}")
+        for c in range(2):
+            for ks in range(8):
+                self.e(f"ds_read_b128 {ar(Q_BASE(c, ks), 4)}, {vr(T(ks))} offset:{c * 32 * 256}")
+        self.e("s_waitcnt lgkmcnt(0)")
+        return self.out
+
+
+ABLATIONS = [("dma",), ("sm",), ("lds",), ("dma", "sm", "lds"), ("dma", "lds"), ("wait",), ("cvt",), ("dma", "sm")]
 
 
 # ---- operand / clobber lists (C++ names of mfa_prefill64.hip) -------------------------------------------------------------
-S_TMP = [f"s{i}" for i in range(84, 100)]
+S_TMP = [f"s{i}" for i in range(84, 86)]
 C_OP = '[c] "s"(c_log2)'
 
 
@@ -583,6 +680,8 @@ def rng(kind, lo, n):
 
 def pin(kind, lo, n, mode=""):
     lo += VB if kind == "v" else AB
+    if n == 1:
+        return f'"{mode}{{{kind}{lo}}}"'
     return f'"{mode}{{{kind}[{lo}:{lo + n - 1}]}}"'
 
 
@@ -602,48 +701,52 @@ def emit_block(fh, name, lines_of, outs, ins, exclude=()):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "mini-flash-attention_amd", "csrc", "mfa_prefill64_stream.inc")
-    KS, VS = '[kslot] "+s"(k_slot_off)', '[vslot] "+s"(v_slot_off)'
-    steady_outs = ['[j] "+s"(j)', KS, VS, '[status] "=&s"(status)']
-    steady_ins = ['[jend] "s"(jend)', '[kbase] "s"(kbase)', '[vbase] "s"(vbase)', '[ksb] "s"(k_sb)', '[vsb] "s"(v_sb)',
-                  '[dst0] "s"(dma_dst0)', C_OP]
+    KS, VS = '[kslot] "s"(kslot)', '[vslot] "s"(vslot)'
+    steady_outs = ['[j] "+s"(j)', '[koff] "+s"(k_off)', '[voff] "+s"(v_off)', '[status] "=&s"(status)']
+    steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[ksrd] "s"(k_srd)', '[vsrd] "s"(v_srd)', '[k16] "s"(k_step)',
+                  '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)', C_OP]
     with open(path, "w") as fh:
         fh.write("// GENERATED by tools/gen_p64_stream.py -- do not edit.  The instruction streams of prefill64_kernel as inline-asm\n")
         fh.write("// blocks (one text per element type) with their operand lists; register map in the generator's docstring.\n")
         fh.write("// Use:  asm volatile(NAME_F16 NAME_OPS);  inside prefill64_kernel (the operand names are its variables).\n\n")
         # operands -> home registers (pinned inputs; everything else of the reserved range is zeroed or clobbered)
-        q_ins = [pin("a", Q_BASE(c, ks), 4) + f"(Q[{c}][{ks}])" for c in range(2) for ks in range(8)]
-        fixed_ins = q_ins + [pin("v", VRD(0), 4) + "(v_rd)", pin("v", V_KGO, 4) + "(dma_c)", pin("v", QHI(0), 3) + "(row_c)"]
-        fixed_regs = rng("a", 128, 64) + rng("v", VRD(0), 4) + rng("v", V_KGO, 4) + rng("v", QHI(0), 3)
-        krd_regs = rng("v", KRD(0), 8)
-        emit_block(fh, "P64_INIT", lambda st: st.init_block(), [], fixed_ins + [pin("v", KRD(0), 8) + "(k_rd)"],
-                   exclude=fixed_regs + krd_regs)
-        emit_block(fh, "P64_INIT_X0", lambda st: st.init_x0_block(), [KS, pin("v", KRD(0), 8, "+") + "(k_rd)"], fixed_ins,
-                   exclude=fixed_regs + krd_regs)
+        fixed_ins = [pin("v", KRD(0), 8) + "(k_rd)", pin("v", VRD(0), 4) + "(v_rd)", pin("v", V_KGO, 2) + "(dma_go)",
+                     pin("v", QGO[0], 2) + "(q_go01)", pin("v", QGO[2], 2) + "(q_go23)", pin("v", H4, 1) + "(h4)"]
+        fixed_regs = (rng("v", KRD(0), 8) + rng("v", VRD(0), 4) + rng("v", V_KGO, 2) + rng("v", QGO[0], 2) +
+                      rng("v", QGO[2], 2) + rng("v", H4, 1))
+        emit_block(fh, "P64_SETUP", lambda st: st.setup_block(), [], fixed_ins, exclude=fixed_regs)
+        emit_block(fh, "P64_DMA_Q", lambda st: st.dma_q_block(), ['[off] "+s"(dma_off)'],
+                   ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
+        emit_block(fh, "P64_Q_LDS", lambda st: st.q_lds_block(), [], ['[qoff] "s"(q_lds_off)'])
+        emit_block(fh, "P64_X0", lambda st: st.x0_block(), [], [KS, '[qhi0] "v"(qhi0)', '[qhi1] "v"(qhi1)'])
         emit_block(fh, "P64_FIRST0", lambda st: st.first_block(0), [], [C_OP])
-        emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [KS], [C_OP])
+        emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [], [KS, C_OP])
         emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
-        for tag in ("dma", "sm", "lds"):  # timing-only variants of the steady loop (results are wrong): MFA_P64_DEBUG bits 2..4
-            def ablated(st, tag=tag):
-                st.ablate = {tag}
+        # timing-only variants of the steady loop (results are wrong): MFA_P64_DEBUG >> 2 = 1 + index
+        for n, tags in enumerate(ABLATIONS):
+            def ablated(st, tags=tags):
+                st.ablate = set(tags)
                 return st.steady()
-            emit_block(fh, f"P64_STEADY_NO_{tag.upper()}", ablated, steady_outs, steady_ins)
+            emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins)
         for pn in range(2):
-            emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [KS], [C_OP])
-            emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [VS], [])
-            emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [VS], [C_OP])
+            emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
+            emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
+            emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [], [VS, C_OP])
             emit_block(fh, f"P64_SM2_{pn}", lambda st, pn=pn: st.sm_second_half(pn), [], [C_OP])
             emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], ['[skm1] "s"(skm1)', '[j64] "s"(j64)'])
             for ch in range(2):
                 emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [],
-                           ['[skm1] "s"(skm1)', '[j64] "s"(j64)', '[kdelta] "s"(kdelta)', C_OP])
+                           ['[skm1] "s"(skm1)', '[j64] "s"(j64)', KS, C_OP])
         emit_block(fh, "P64_CHECK", lambda st: st.check_block(), ['[status] "=&s"(status)'], [])
         for nm, isv in (("P64_DMA_K", False), ("P64_DMA_V", True)):
-            emit_block(fh, nm, lambda st, isv=isv: st.dma_block(isv), [],
-                       ['[off] "s"(dma_off)', '[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[base] "s"(dma_base)'])
+            emit_block(fh, nm, lambda st, isv=isv: st.dma_block(isv), ['[off] "+s"(dma_off)'],
+                       ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
+        emit_block(fh, "P64_EPILOGUE", lambda st: st.epilogue_block(), [],
+                   ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[osb4] "s"(o_step)'],
+                   exclude=rng("v", L(0), 2) + rng("v", M(0), 2))
         # home registers -> operands: an empty statement whose outputs are pinned to the homes
-        o_outs = [pin("a", O_BASE(c, d), 16, "=") + f"(O[{c}][{d}])" for c in range(2) for d in range(4)]
         fh.write('#define P64_FINAL_F16 ""\n#define P64_FINAL_BF16 ""\n')
-        fh.write("#define P64_FINAL_OPS : " + ", ".join(o_outs + [pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
+        fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
                  " : : \"memory\"\n")
     print("wrote", os.path.relpath(path, root))
 

@@ -6,7 +6,7 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 causal = bool(int(sys.argv[2])) if len(sys.argv) > 2 else True
 B, H, D = 48, 24, 128
 nwg = 8 * ((B * H + 7) // 8 // 4 + 1) * 4 * ((S + 255) // 256) + 64
-dbg = torch.zeros(nwg * 8, device="cuda", dtype=torch.int64)
+dbg = torch.zeros(nwg * 16, device="cuda", dtype=torch.int64)
 os.environ["MFA_P64_DBGPTR"] = str(dbg.data_ptr())
 os.environ["MFA_P64_DEBUG"] = str(2 | (int(sys.argv[3]) if len(sys.argv) > 3 else 0))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
@@ -17,11 +17,11 @@ for _ in range(5):
 dbg.zero_()
 mfa.flash_attn_func(q, k, v, causal=causal)
 torch.cuda.synchronize()
-d = dbg.view(-1, 8).cpu()
+d = dbg.view(-1, 16).cpu()
 d = d[d[:, 0] != 0]
 nt = (d[:, 7] >> 32).float(); ntw = (d[:, 7] & 0xffffffff).float()
 t0 = d[:, 0].min().item()
-names = ["entry->ready (Q + first tiles)", "ready->init done", "init->first tiles done (X0, softmax, X1)", "loop: first steady block", "loop total",
+names = ["prev item done->barrier", "tile DMA issue", "init->first tiles done (X0, softmax, X1)", "loop: first steady block", "loop total",
          "epilogue"]
 seg = [(0, 1), (1, 2), (2, 3), (3, 4), (3, 5), (5, 6)]
 print(f"S={S} causal={causal}: {len(d)} workgroups, kernel span {(d[:, 6].max().item() - t0)} cycles (100 MHz? see below)")
@@ -36,3 +36,13 @@ for ntv in sorted(set(nt.tolist())):
     row.append(f"total {tot.mean().item():9.0f}")
     print(" ".join(row))
 print("columns:", " | ".join(names))
+x = (d[:, 1] - d[:, 0]).float()
+print(f"  item boundary (end of previous epilogue -> barrier passed): mean {x.mean().item():7.0f} min {x.min().item():7.0f} p50 {x.median().item():7.0f} max {x.max().item():7.0f}")
+
+m = nt == nt.max()
+for i in range(1, -1, -1):
+    a = (d[m, 9 + 2 * i] - d[m, 8 + 2 * i]).float(); b = ((d[m, 8 + 2 * (i - 1)] if i else d[m, 5]) - d[m, 9 + 2 * i]).float()
+    print(f"  iteration nt-{i}: barrier wait {a.mean().item():7.0f}  body {b.mean().item():7.0f}")
+for a, b, nm in ((12, 13, "decode + context"), (13, 14, "K0' K1' V0' DMA issue"), (14, 15, "Q' DMA issue")):
+    x = (d[m, b] - d[m, a]).float()
+    print(f"  prefetch {nm:24s} {x.mean().item():7.0f}")
