@@ -9,6 +9,12 @@ A "step" is one pass of the hot path over one batch of synthetic input, already 
     FLOPs = 4*B*H*S^2*D / 2);
   * "decode" object: BASELINE config 3 — bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128, num_splits auto, timed the
     same way right after, reported as HBM GB/s of the algorithmic bytes (K+V once per KV head, + Q + O).
+Beside the contract's timed region (N=1 only, outside it): "sweep" — the reference benchmark's prefill shape family
+(fp16 B=48 H=24 D=128, S = 256 .. 4096, causal and not), and "decode_sweep" — the reference README's MHA fp16
+decode shapes (B=24 H=24 Skv = 512 .. 8192) and BASELINE config 5 (paged), each over ROTATING cache copies so no
+launch finds its cache in the 256 MB Infinity Cache.  Every sweep entry carries two regimes: "cold" = the first 25
+launches after an idle gap (what a short driver run sees: clocks and power have not settled) and "steady" = after
+about half a second of back-to-back launches.
 Multi-GPU: the path is embarrassingly parallel over batch x heads and has no exchange step ("replicas only",
 DESIGN.md): every rank runs its own batch (weak scaling), the timed region is bracketed by barrier +
 synchronize, elapsed = MAX over ranks, value = all ranks' work / that time.
@@ -32,6 +38,9 @@ PEAK_HBM_GBPS = 8000.0     # HBM3E spec (≈6300 achievable copy)
 
 PREFILL = dict(B=48, S=1024, H=24, Hk=24, D=128, causal=True, dtype=torch.float16)
 DECODE = dict(B=24, Sk=8192, H=24, Hk=8, D=128, dtype=torch.bfloat16)
+SWEEP_S = (256, 512, 1024, 2048, 4096)
+DECODE_SWEEP_SK = (512, 1024, 2048, 4096, 8192)
+PAGED = dict(B=16, Sk=4096, H=24, Hk=8, D=128, page=256, dtype=torch.bfloat16)
 
 
 def prefill_flops(c):
@@ -81,6 +90,32 @@ def timed_region(fn, steps, warmup, dist):
     return wall, ev_ms
 
 
+def event_ms(fn, n):
+    """mean device ms per launch over n back-to-back launches (HIP events on the launch stream)"""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(n):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / n
+
+
+def cold_and_steady(fn, cold_n=25, settle_s=0.5, steady_n=40, idle_s=0.25):
+    """(cold ms, steady ms): the first cold_n launches after an idle gap, then steady_n launches after settle_s of
+    back-to-back launches.  One launch beforehand loads the code object and is not timed."""
+    fn()
+    torch.cuda.synchronize()
+    time.sleep(idle_s)
+    cold = event_ms(fn, cold_n)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+    return cold, event_ms(fn, steady_n)
+
+
 def cpu_baseline(c, budget_s=20.0):
     """Eager torch SDPA, fp32, on the host cores (what reference tests/test_mha.py:75-81 uses as its oracle),
     on a batch slice of the headline workload sized to ~budget_s of CPU work."""
@@ -108,6 +143,75 @@ def cpu_baseline(c, budget_s=20.0):
     }
 
 
+def prefill_sweep(mfa, dev):
+    """fp16 B=48 H=24 D=128, S in SWEEP_S, causal and not: TFLOP/s and both roofline fractions, cold and steady"""
+    out = []
+    for S in SWEEP_S:
+        c = dict(PREFILL, S=S)
+        q, k, v = (torch.randn(c["B"], S, c["H"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"]) for _ in range(3))
+        for causal in (True, False):
+            c["causal"] = causal
+            n = max(4, min(40, int(0.25 / (prefill_flops(c) / 0.9e15))))
+            cold, steady = cold_and_steady(lambda: mfa.flash_attn_func(q, k, v, causal=causal), steady_n=n,
+                                           settle_s=max(0.5, 25 * prefill_flops(c) / 0.9e15))
+            ent = {"S": S, "causal": causal}
+            for nm, ms in (("cold", cold), ("steady", steady)):
+                tf, gb = prefill_flops(c) / ms / 1e9, prefill_bytes(c) / ms / 1e6
+                ent[nm] = {"ms": round(ms, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK_MFMA_TFLOPS, 4),
+                           "hbm_gbps": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBPS, 4)}
+            out.append(ent)
+        del q, k, v
+    return out
+
+
+def decode_sweep(mfa, dev):
+    """README MHA fp16 decode shapes (B=24 H=24 D=128 Sq=1) and BASELINE config 5 (paged), over rotating cache copies"""
+    out = []
+    for Sk in DECODE_SWEEP_SK:
+        c = dict(B=24, Sk=Sk, H=24, Hk=24, D=128)
+        copies = max(2, min(8, -(-int(1.5e9) // int(decode_bytes(c)))))
+        sets = [tuple(torch.randn(c["B"], Sk, c["Hk"], c["D"], device=dev, dtype=torch.float16) for _ in range(2)) for _ in range(copies)]
+        q = torch.randn(c["B"], 1, c["H"], c["D"], device=dev, dtype=torch.float16)
+        lens = torch.full((c["B"],), Sk, dtype=torch.int32, device=dev)
+        st = {"i": 0}
+
+        def run():
+            kc, vc = sets[st["i"] % copies]
+            st["i"] += 1
+            mfa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, num_splits=0)
+
+        cold, steady = cold_and_steady(run, steady_n=40, settle_s=0.3)
+        ent = {"workload": f"decode fp16 MHA B=24 Sq=1 Skv={Sk} H=24 D=128 num_splits=auto", "rotating_copies": copies}
+        for nm, ms in (("cold", cold), ("steady", steady)):
+            gb = decode_bytes(c) / ms / 1e6
+            ent[nm] = {"us": round(ms * 1e3, 2), "hbm_gbps": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBPS, 4)}
+        out.append(ent)
+        del sets, q
+    p = PAGED
+    nb = p["Sk"] // p["page"]
+    sets = []
+    for _ in range(4):
+        kp, vp = (torch.randn(p["B"] * nb, p["page"], p["Hk"], p["D"], device=dev, dtype=p["dtype"]) for _ in range(2))
+        sets.append((kp, vp, torch.randperm(p["B"] * nb, device=dev).int().view(p["B"], nb)))
+    q = torch.randn(p["B"], 1, p["H"], p["D"], device=dev, dtype=p["dtype"])
+    lens = torch.full((p["B"],), p["Sk"], dtype=torch.int32, device=dev)
+    st = {"i": 0}
+
+    def run_paged():
+        kp, vp, table = sets[st["i"] % 4]
+        st["i"] += 1
+        mfa.flash_attn_with_kvcache(q, kp, vp, cache_seqlens=lens, block_table=table)
+
+    cold, steady = cold_and_steady(run_paged, steady_n=40, settle_s=0.3)
+    ent = {"workload": "paged decode bf16 B=16 Sq=1 Skv=4096 Hq=24 Hkv=8 D=128 page=256, permuted block table (BASELINE config 5)",
+           "rotating_copies": 4}
+    for nm, ms in (("cold", cold), ("steady", steady)):
+        gb = decode_bytes(p) / ms / 1e6
+        ent[nm] = {"us": round(ms * 1e3, 2), "hbm_gbps": round(gb, 1), "hbm_frac": round(gb / PEAK_HBM_GBPS, 4)}
+    out.append(ent)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,6 +220,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,7 +258,8 @@ def main():
     else:
         roof = {"bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4)}
-    roof.update({"traffic": measured_traffic("prefill"), "kernel": "prefill_fwd_kernel<Half,128>", "kernel_ms": round(ev_ms, 4),
+    roof.update({"traffic": measured_traffic("prefill"), "traffic_source": "profiles/traffic.json (replayed)",
+                 "kernel": "prefill64_kernel<Half>", "kernel_ms": round(ev_ms, 4),
                  "mfma_tflops": round(kern_tflops, 1), "mfma_frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4),
                  "hbm_gbps": round(kern_gbps, 1), "hbm_frac": round(kern_gbps / PEAK_HBM_GBPS, 4),
                  "algorithmic_flops": prefill_flops(c), "algorithmic_bytes": prefill_bytes(c)})
@@ -174,6 +280,7 @@ def main():
         "config": {"workload": "flash-decoding bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128 num_splits=auto (BASELINE config 3)"},
         "roofline": {"bound": "hbm", "achieved": round(dec_kern_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(dec_kern_gbps / PEAK_HBM_GBPS, 4), "traffic": measured_traffic("decode"),
+                     "traffic_source": "profiles/traffic.json (replayed)",
                      "kernel": "decode_split_kv_kernel + decode_combine_kernel", "kernel_us": round(dev_ms * 1e3, 2),
                      "algorithmic_bytes": decode_bytes(d)},
     }
@@ -193,6 +300,14 @@ def main():
                      "kernel": "prefill_fwd_kernel<MQ> + decode_combine_kernel", "kernel_us": round(gev_ms * 1e3, 2),
                      "algorithmic_bytes": decode_bytes(g8)},
     }
+    del qg, kc, vc
+
+    sweeps = {}
+    if n_gpus == 1 and not dist and not args.no_sweep:  # outside the timed regions; a few seconds each
+        sweeps["sweep"] = prefill_sweep(mfa, dev)
+        sweeps["decode_sweep"] = decode_sweep(mfa, dev)
+        sweeps["regimes"] = ("cold = mean of the first 25 launches after a 0.25 s idle gap; steady = mean of 4-40 launches "
+                             "after >= 0.3-0.5 s of back-to-back launches; HIP events on the launch stream")
 
     if rank == 0:
         out = {
@@ -204,6 +319,7 @@ def main():
                        "parallelism": f"replicas x{n_gpus} (no collective on the data path)"},
             "roofline": roof, "decode": decode, "kvcache_packed": packed,
         }
+        out.update(sweeps)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)
         print(json.dumps(out), flush=True)

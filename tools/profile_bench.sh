@@ -12,10 +12,10 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="$ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-sweep"
 # the --stats average is over EVERY launch, warm-up included (cold clocks, first-touch): enough timed steps that the
 # steady state bench.py reports dominates it
-ARGS_STATS="$ROOT/bench.py --steps 300 --warmup 10 --no-cpu-baseline"
+ARGS_STATS="$ROOT/bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-sweep"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $ARGS_STATS > "$OUT/stats.log" 2>&1 || exit 1
 [ "${2:-}" = "stats-only" ] && exit 0
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/pmc_fetch" -- python3 $ARGS > "$OUT/pmc_fetch.log" 2>&1 || exit 2

@@ -38,7 +38,10 @@ def main(tag, name):
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(rows)
-    summary = {"source": f"rocprofv3 over `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline` (tools/profile_bench.sh {tag})",
+    summary = {"source": f"tools/profile_bench.sh {tag}: calls / avg_us / min_us / max_us from `rocprofv3 --kernel-trace --stats -- "
+                         "python3 bench.py --steps 300 --warmup 10 --no-cpu-baseline --no-sweep` (every launch, warm-up included); "
+                         "the counters from separate `rocprofv3 --pmc ... -- python3 bench.py --steps 20 --warmup 5 "
+                         "--no-cpu-baseline --no-sweep` passes (FETCH_SIZE | WRITE_SIZE | SQ_*), averaged over their launches",
                "kernels": {}}
     pm = {k: counters(os.path.join(src, k, "*", "*_counter_collection.csv")) for k in ("pmc_fetch", "pmc_write", "pmc_sq")}
     for r in rows:
@@ -64,7 +67,7 @@ def main(tag, name):
                          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction)"}
     for k, e in summary["kernels"].items():
         if "hbm_traffic_bytes" in e:
-            key = "prefill" if "prefill" in k else ("decode" if "decode_split" in k else None)
+            key = "prefill" if "prefill64_kernel" in k else ("decode" if "decode_split" in k else None)
             if key:
                 traffic[key] = e["hbm_traffic_bytes"]
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
