@@ -48,8 +48,11 @@ enum {
     MFA_ERR_WORKSPACE = -4         /* split decode requested without oaccum / lseaccum buffers  */
 };
 
-/* Mirrors mfa::ForwardParams (csrc/mfa/flash.h:8-73) field for field, plus three additive
- * fields at the end that the reference leaves implicit (total_k, num_cus, reserved). */
+/* Carries the fields of mfa::ForwardParams (csrc/mfa/flash.h:8-73) under the same names and in the same order,
+ * as a plain-C layout of its own: bool -> int32_t, int / size_t strides -> int64_t, void* -> typed pointers, and
+ * max_seqlen_q / max_seqlen_k folded into seqlen_q / seqlen_k (api.cpp:236 passes the maxima as the lengths).  It is NOT
+ * layout-compatible with the C++ struct: a host fills it field by field (INTEGRATION.md shows the copy).  Nine
+ * additive fields follow the reference's (max_blocks_per_seq .. reserved), all "off" when zero. */
 typedef struct mfa_forward_params {
     const void* q_ptr; /* (B,Sq,H,D) or varlen (total_q,H,D)                                   */
     const void* k_ptr; /* (B,Sk,Hkv,D), varlen (total_k,Hkv,D) or paged (nblk,page,Hkv,D)     */

@@ -41,6 +41,8 @@ ForwardParams = _capi.ForwardParams
 
 def build(force: bool = False) -> str:
     """gcc the restatement into oracle/_build/libmfa_oracle.so (plain C, OpenMP over (batch, head))."""
+    if os.environ.get("MFA_TEST_ORACLE_LIB"):  # tests/test_sanitizers_cpu.py: a build with -fsanitize=address,undefined
+        return os.environ["MFA_TEST_ORACLE_LIB"]
     hdr = os.path.join(_ROOT, "include", "mfa.h")
     if not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= max(os.path.getmtime(_SRC), os.path.getmtime(hdr)):
         return _LIB

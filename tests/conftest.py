@@ -64,6 +64,36 @@ def assert_close(out, ref, out_dtype=None, atol=ATOL, rtol=RTOL, what="", p_roun
                         f"exceeds atol+rtol*|ref|+half_ulp by {worst:.3e}")
 
 
+def strict_report(out, ref, name, must_pass=True, why=""):
+    """The literal north_star bar: |out - ref_fp32| <= 1e-3 + 1e-3*|ref| -- no half-ulp of the output type, no
+    P-rounding slack.  Records max / mean error and the violating fraction under `name` in parity_r02.json (written
+    beside the other run outputs: gpurun_out/ on the GPU box, copied to profiles/); asserts when must_pass."""
+    import json
+    o, r = out.detach().float().cpu(), ref.detach().float().cpu()
+    assert o.shape == r.shape and torch.isfinite(o).all(), name
+    err = (o - r).abs()
+    bad = err > ATOL + RTOL * r.abs()
+    rec = {"max_abs_err": float(err.max()), "mean_abs_err": float(err.mean()), "max_abs_ref": float(r.abs().max()),
+           "violating_fraction": float(bad.float().mean()), "elements": int(err.numel()), "out_dtype": str(out.dtype),
+           "bar": "|out - ref| <= 1e-3 + 1e-3*|ref| (strict)", "meets_bar": not bool(bad.any())}
+    if why:
+        rec["note"] = why
+    outdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, "parity_r02.json")
+    try:
+        with open(path) as f:
+            allrec = json.load(f)
+    except (OSError, ValueError):
+        allrec = {}
+    allrec[name] = rec
+    with open(path, "w") as f:
+        json.dump(allrec, f, indent=1, sort_keys=True)
+    if must_pass:
+        assert not bad.any(), f"{name}: strict bar violated by {rec['violating_fraction']:.2e} of elements, max|err|={rec['max_abs_err']:.3e}"
+    return rec
+
+
 def from_bits(a, dtype):
     """uint16 numpy array (golden fixture) -> torch tensor of fp16/bf16 with the same bits."""
     return torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).view(dtype)
@@ -92,5 +122,7 @@ def capi():
     """ctypes binding of libmfa_hip.so (the C ABI of include/mfa.h)."""
     import torch  # noqa: F401  (load torch's HIP runtime first so both share it)
     from mini_flash_attention import capi as c
+    if os.environ.get("MFA_TEST_CAPI_LIB"):  # tests/test_sanitizers_cpu.py: the host half alone, sanitized, no kernels
+        c.load(os.environ["MFA_TEST_CAPI_LIB"])
     c.load()
     return c

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import hip_path as hp
-from conftest import P_ROUND_ATOL, assert_close, from_bits, load_golden
+from conftest import strict_report, P_ROUND_ATOL, assert_close, from_bits, load_golden
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -24,18 +24,23 @@ def test_golden_g1_g2_g4(route, mfa, capi):
         q, k, v = (torch.from_numpy(g[n]).to(dt).to(DEV) for n in "qkv")
         out = hp.prefill(route, mfa, capi, q, k, v)
         assert_close(out, hp.sdpa_gpu(q, k, v), p_rounded=True, what=f"g1 {dt}")
+        if dt == torch.float16:
+            strict_report(out, hp.sdpa_gpu(q, k, v), f"config1 g1 fp16 ({route})")
         # fp32 fixture vs 16-bit inputs: input rounding dominates; the reference's own bar (test_mha.py:90-91)
         d = (out.float().cpu() - torch.from_numpy(g["expect"])).abs()
         assert d.max() < 0.02 and d.mean() < 0.002
     g = load_golden("g2_fp16_causal_d128")
     for i in range(int(g["n"])):
         q, k, v = (from_bits(g[f"{n}{i}"], torch.float16).to(DEV) for n in "qkv")
-        assert_close(hp.prefill(route, mfa, capi, q, k, v, True), torch.from_numpy(g[f"expect{i}"]), p_rounded=True, what=f"g2[{i}]")
+        out = hp.prefill(route, mfa, capi, q, k, v, True)
+        assert_close(out, torch.from_numpy(g[f"expect{i}"]), p_rounded=True, what=f"g2[{i}]")
+        strict_report(out, torch.from_numpy(g[f"expect{i}"]), f"config2-shaped golden g2[{i}] fp16 causal D128 ({route})")
     g = load_golden("g4_fp16_varlen_h8_d64")
     q, k, v = (from_bits(g[n], torch.float16).to(DEV) for n in "qkv")
     cu = torch.from_numpy(g["cu"]).to(DEV)
     out = hp.prefill(route, mfa, capi, q, k, v, True, cu_q=cu, cu_k=cu, max_sq=512, max_sk=512)
     assert_close(out, torch.from_numpy(g["expect"]), p_rounded=True, what="g4 (BASELINE config 4)")
+    strict_report(out, torch.from_numpy(g["expect"]), f"config4 g4 fp16 varlen H8 D64 causal ({route})")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
@@ -186,6 +191,7 @@ def test_baseline_config2_full_size(mfa, capi):
     out = hp.prefill("api", mfa, capi, q, k, v, True)
     for b in (0, 17, 47):
         assert_close(out[b:b + 1], hp.sdpa_gpu(q[b:b + 1], k[b:b + 1], v[b:b + 1], True), p_rounded=True, what=f"config2 batch {b}")
+        strict_report(out[b:b + 1], hp.sdpa_gpu(q[b:b + 1], k[b:b + 1], v[b:b + 1], True), f"config2 full size fp16 B48 S1024 H24 D128 causal, batch {b}")
     assert torch.equal(hp.prefill("capi", mfa, capi, q, k, v, True), out)
     pb = torch.randperm(B, device=DEV)
     ph = torch.randperm(H, device=DEV)
