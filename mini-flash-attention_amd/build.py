@@ -25,9 +25,7 @@ HIP_FLAGS = [
     f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-fno-math-errno",
     "-Wno-unused-result", "-mllvm", "-amdgpu-early-inline-all=true",
 ]
-if os.environ.get("MFA_ABLATION"):  # developer builds only: timing-only kernel variants selected by $MFA_ABLATE
-    HIP_FLAGS.append("-DMFA_ABLATION")
-if os.environ.get("MFA_EXTRA_HIPCC_FLAGS"):  # developer experiments with backend scheduling options
+if os.environ.get("MFA_EXTRA_HIPCC_FLAGS"):  # developer builds: csrc/mfa_dev.h switches (-DMFA_DEV_*), backend options
     HIP_FLAGS += os.environ["MFA_EXTRA_HIPCC_FLAGS"].split()
 
 

@@ -200,7 +200,7 @@ enum { kKvDecode = 0, kKvPacked = 1, kKvPrefill = 2 };
 static int kvcache_route(const mfa_forward_params* p) {
     static const int env = [] { const char* e = getenv("MFA_KVCACHE_PACKED"); return e ? atoi(e) : -1; }();
     const int g = p->kv_heads > 0 ? p->heads / p->kv_heads : 1;
-    const bool has_packed = p->head_dim == 64 || p->head_dim == 128 || p->head_dim == 256;
+    const bool has_packed = p->head_dim == 32 || p->head_dim == 64 || p->head_dim == 96 || p->head_dim == 128 || p->head_dim == 256;
     const int64_t rows = static_cast<int64_t>(p->seqlen_q) * g;
     // (paged caches: the vector kernel resolves a page per key on the VALU and drops to 4.5-4.9 TB/s for groups of 3-4;
     //  the packed kernel's row-gather DMA holds 5.3-5.6: profiles/r01d_kvcache_paged_routes.txt)

@@ -18,11 +18,13 @@
 //   * O leaves through LDS as whole rows (16-byte coalesced stores);
 //   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
 //     run on one XCD (shared L2), heaviest causal blocks first.
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
 #include "mfa_device.h"
 #include "mfa_launch.h"
+#include "mfa_dev.h"
 #include "mfa_prefill_args.h"
 
 namespace mfa {
@@ -60,8 +62,12 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 //   of 1..a few dozen) or a large GQA group, where one query head alone would leave the 32-row MFMA tiles almost
 //   empty and every head would re-stream the same K/V.  Same tile loop; only the row -> (position, head) mapping,
 //   the key range (a split) and the destination (final O, or normalised partials for decode_combine_kernel) differ.
-template <typename T, int D, int NW, bool PAGED, int ABL = 0, bool MQ = false, bool STREAM = false>
-__global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
+// PG: 0 = dense K/V; 1 = paged, any page size (a block-table lookup per staged row); 2 = paged with page_size a power
+// of two >= the 64-key tile: a tile lies in one page, one scalar lookup per tile (reference decode.cuh:50-55 resolves
+// the same way).
+template <typename T, int D, int NW, int PG, bool MQ = false, bool STREAM = false>
+__global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) ? 2 : 1)) void prefill_fwd_kernel(const PrefillArgs a) {
+    constexpr bool PAGED = PG != 0;
     using E = Elem<T>;
     using frag8 = typename E::frag8;
     constexpr int RB = Pitch<D>::RB;
@@ -83,9 +89,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31;
     const int h = lane >> 5;
-    // (developer builds, ABL & 1024: phase timestamps of every workgroup go to the LSE buffer; tools/wg_timeline.py)
-    long long stamp[4] = {0, 0, 0, 0};
-    if constexpr ((ABL & 1024) != 0) stamp[0] = wall_clock64();
+    MFA_DEV_STAMP_DECL; // (developer builds only: mfa_dev.h)
 
     // ---- workgroup -> (batch, head, query block) -------------------------------------------------
     // XCD-aware: blocks bid, bid+8, ... share an XCD (round-robin dispatch), so XCD x = bid & 7 owns a contiguous
@@ -165,8 +169,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     auto row_pos = [&](int row) { return MQ ? row / G : row; };
     auto row_off = [&](int row, int64_t row_stride, int64_t head_stride) -> int64_t {
         if constexpr (!MQ) return (int64_t)row * row_stride;
+        // (packed rows address one batch element's Q / O: the launcher keeps that below 2^31 elements, so the
+        // arithmetic stays in 32 bits and the strides in one scalar register each)
         const int pos = row / G;
-        return (int64_t)pos * row_stride + (int64_t)(row - pos * G) * head_stride;
+        return (int64_t)(pos * (int)row_stride + (row - pos * G) * (int)head_stride);
     };
 
     // key window of query position r: [r + lo, r + hi] intersected with [0, sk)  (top-left: off = 0, the reference's
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // once): the DMA uses the non-temporal policy, which lifts the achievable HBM rate from 5.8-6.0 to 6.8-6.9 TB/s
     // (tools/probes/stream_probe.hip).  Prefill, and packed launches whose row blocks re-read K/V out of L2, keep the
     // default policy (prefill with nt: -20...-30 %).
-    constexpr bool DMA_NT = STREAM || (ABL & 2048) != 0;
+    constexpr bool DMA_NT = STREAM || MFA_DEV_ABL(2048);
     const int last_key = max(sk - 1, 0);
     const int srow = wave * RPI + lane / LPR_; // row of this lane inside instruction 0 (+ i*RPI*NW for instruction i)
     const int spos = lane % LPR_;
@@ -230,9 +236,22 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     const uint32_t k_go = srow * k_sb + 16 * s_kch, v_go = srow * v_sb + 16 * s_vch;
     const uint32_t k_gmax = last_key * k_sb + 16 * s_kch, v_gmax = last_key * v_sb + 16 * s_vch;
     // paged K/V: page id of each of this lane's NI rows of the NEXT tile to be fetched
-    int pid_n[NI];
+    // (PG == 1: the page strides live in VGPRs -- these instances sit at the scalar-register limit, where the backend
+    // reserves an emergency stack slot it never uses)
+    auto in_vgpr = [](int64_t x) {
+        uint32_t lo, hi;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(lo), "=v"(hi) : "s"((uint32_t)x), "s"((uint32_t)((uint64_t)x >> 32)));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int64_t k_page_bytes = PG == 1 ? in_vgpr(2 * a.k_block_stride) : 0, v_page_bytes = PG == 1 ? in_vgpr(2 * a.v_block_stride) : 0;
+    int pid_n[PG == 1 ? NI : 1];
+    const char *kpage_n = nullptr, *vpage_n = nullptr; // PG == 2: page bases of the next tile to be fetched
     auto load_pids = [&](int j) {
-        if constexpr (PAGED) {
+        if constexpr (PG == 2) { // one page per tile: a wave-uniform (scalar) block-table load
+            const int64_t pid = __builtin_amdgcn_readfirstlane(table[min((j * kBN) >> a.page_shift, a.max_blocks - 1)]);
+            kpage_n = kbase + 2 * pid * a.k_block_stride;
+            vpage_n = vbase + 2 * pid * a.v_block_stride;
+        } else if constexpr (PG == 1) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int key = min(j * kBN + i * RPI * NW + srow, last_key);
@@ -252,15 +271,21 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         // the uniformity provable for the "s" operand
         const uint32_t dst = __builtin_amdgcn_readfirstlane(
             smem_lds + (is_v ? 2 * TILE_BYTES : 0) + BUF * TILE_BYTES + (row + wave * RPI) * RB);
-        if constexpr (PAGED) {
+        if constexpr (PG == 2) {
+            // the tile's page id is wave-uniform: page base on the scalar side, the row inside the page as a 32-bit
+            // lane offset (the dense path's addressing; rows past the last key clamp to it, in the same page)
+            const uint32_t in = (uint32_t)(min(j * kBN + row + srow, last_key) & (a.page_size - 1));
+            if (is_v) lds_dma16<DMA_NT>(vpage_n, in * v_sb + 16 * s_vch, dst);
+            else lds_dma16<DMA_NT>(kpage_n, in * k_sb + 16 * k_src_chunk(srow + row), dst);
+        } else if constexpr (PG == 1) {
             // page ids were looked up one tile earlier (pid_n): a block-table load right here would be waited for by
             // the compiler with a vmcnt that also drains every DMA piece issued before it
             const int key = min(j * kBN + row + srow, last_key);
             const int pg = a.page_shift >= 0 ? (key >> a.page_shift) : (key / a.page_size);
             const int in = a.page_shift >= 0 ? (key & (a.page_size - 1)) : (key - pg * a.page_size);
             const int64_t pid = pid_n[is_v ? pc - NI : pc];
-            if (is_v) lds_dma16<DMA_NT>(vbase + 2 * (pid * a.v_block_stride + (int64_t)in * a.v_row_stride) + 16 * s_vch, dst);
-            else lds_dma16<DMA_NT>(kbase + 2 * (pid * a.k_block_stride + (int64_t)in * a.k_row_stride) + 16 * k_src_chunk(srow + row), dst);
+            if (is_v) lds_dma16<DMA_NT>(vbase + pid * v_page_bytes + ((uint32_t)in * v_sb + 16 * s_vch), dst);
+            else lds_dma16<DMA_NT>(kbase + pid * k_page_bytes + ((uint32_t)in * k_sb + 16 * k_src_chunk(srow + row)), dst);
         } else {
             const uint32_t rows = (uint32_t)(j * kBN + row);
             if (is_v) {
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
     // MFMAs), which from the second iteration on would drain the just-issued DMA of the next tile.
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
     __syncthreads();
-    if constexpr ((ABL & 1024) != 0) stamp[1] = wall_clock64();
+    MFA_DEV_STAMP(1);
 
     // one key tile out of LDS buffer BUF (compile-time, so every LDS offset is an immediate)
     auto tile = [&](int jj, auto bufc) {
@@ -332,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
         // pieces are issued one per QK^T k-step, between the MFMAs, rather than as a burst: a burst of 1-KiB pieces
         // stalls the wave at issue (the price of a piece depends on what else is in flight).
         constexpr auto nbuf = std::integral_constant<int, BUF ^ 1>{};
-        const bool dma = more && !(ABL & 1);
+        const bool dma = more && !MFA_DEV_ABL(1);
 
         // a wave none of whose rows can see this tile (above the causal diagonal / outside the window) skips it
         const bool active = (!MQ || wave_has_rows) && (!has_hi || j * kBN <= wpos_hi + hi) &&
@@ -405,7 +430,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             // grew its max by more than THR in the exponent; otherwise the old max stays and P may reach 2^THR
             // instead of 1 -- the same relative precision in fp16/bf16 and in the fp32 sums, one O-wide multiply
             // pass less per tile.  THR = 0 is the textbook update (every growth rescales).
-            constexpr float THR = (ABL & 512) ? 0.f : 6.f;
+            constexpr float THR = MFA_DEV_ABL(512) ? 0.f : 6.f;
             if (__builtin_amdgcn_ballot_w64((m_new - m_run) * c > THR) != 0) {
                 const float msn = (m_new == -INFINITY) ? 0.f : m_new;
                 const float alpha = fast_exp2((m_run - msn) * c);
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                 for (int i = 0; i < 8; ++i) {
                     const f32x2 sv = {s[kb][2 * i], s[kb][2 * i + 1]};
                     const f32x2 t = __builtin_elementwise_fma(sv, c2, nmc2);
-                    const f32x2 pv = (ABL & 4) ? t : f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
+                    const f32x2 pv = MFA_DEV_ABL(4) ? t : f32x2{fast_exp2(t[0]), fast_exp2(t[1])};
                     ps2 += pv;
                     pk[kb][i] = E::pack(pv[0], pv[1]);
                 }
@@ -448,23 +473,23 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(va + 8 * RB));
                     typedef short s16x8 __attribute__((ext_vector_type(8)));
                     const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    if (!(ABL & 8)) oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
+                    if (!MFA_DEV_ABL(8)) oacc[d] = E::mfma32(__builtin_bit_cast(frag8, vv), pf, oacc[d]);
                     else oacc[d][0] += (float)vv[0] + (float)vv[4];
                 }
             }
         }
         // the DMA is a pending LDS write on the VM counter: drain it, then let the other waves read the tile
-        if (!(ABL & 64)) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-        if (!(ABL & 2)) __syncthreads();
+        if (!MFA_DEV_ABL(64)) __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
+        if (!MFA_DEV_ABL(2)) __syncthreads();
     };
 
-    if (ABL & 256) nt = 0; // timing-only: prologue + epilogue, no tiles
+    if (MFA_DEV_ABL(256)) nt = 0;
     for (int j = 0; j < nt; j += 2) {
         tile(j, std::integral_constant<int, 0>{});
         if (j + 1 < nt) tile(j + 1, std::integral_constant<int, 1>{});
     }
 
-    if constexpr ((ABL & 1024) != 0) stamp[2] = wall_clock64();
+    MFA_DEV_STAMP(2);
     // ---- epilogue: 1/l (prefill.cuh:600-612), O^T -> LDS rows -> coalesced 16-byte stores ------------
     const float l_tot = l_run + swap32(l_run);
     const float inv = (l_tot == 0.f || l_tot != l_tot) ? 1.f : 1.f / l_tot;
@@ -488,7 +513,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             return;
         }
         if (a.lse && h == 0 && qrow < nrows) a.lse[((int64_t)b * a.heads + hq + grp) * sq + qpos] = lse_row;
-    } else if (!(ABL & 1024) && a.lse && h == 0 && qrow < sq) {
+    } else if (!MFA_DEV_TIMELINE_ON && a.lse && h == 0 && qrow < sq) {
         const int64_t idx = a.cu_q ? (int64_t)hq * a.total_q + a.cu_q[b] + qrow
                                    : ((int64_t)b * a.heads + hq) * a.seqlen_q + qrow;
         a.lse[idx] = lse_row;
@@ -526,19 +551,10 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 ? 2 : 1)) void prefill_fwd_kerne
             if (grow < nrows) *(u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch) = val;
         }
     }
-    if constexpr ((ABL & 1024) != 0) {
-        if (a.lse && tid == 0) {
-            long long* dbg = (long long*)a.lse + (size_t)blockIdx.x * 8;
-            dbg[0] = stamp[0]; dbg[1] = stamp[1]; dbg[2] = stamp[2]; dbg[3] = wall_clock64();
-            dbg[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
-            dbg[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20); // XCC_ID
-            dbg[6] = nt;
-            dbg[7] = 0x5A5A5A5A5A5A5A5ALL;
-        }
-    }
+    MFA_DEV_STAMP_FLUSH(a.lse, tid, nt);
 }
 
-template <typename T, int D, int NW, bool PAGED>
+template <typename T, int D, int NW, int PG>
 static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     constexpr int BM = 32 * NW;
     constexpr int RB = Pitch<D>::RB;
@@ -553,28 +569,7 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
     const int64_t total = 8 * groups * a.group_pairs * a.num_m_blocks;
     if (total > 0x7fffffffLL) return -1;
-    auto kern = prefill_fwd_kernel<T, D, NW, PAGED>;
-#ifdef MFA_ABLATION
-    if constexpr (D == 128 && !PAGED && std::is_same<T, Half>::value) {
-        static const int abl = [] { const char* e = getenv("MFA_ABLATE"); return e ? atoi(e) : 0; }();
-        switch (abl) {
-        case 1: kern = prefill_fwd_kernel<T, D, NW, PAGED, 1>; break;
-        case 3: kern = prefill_fwd_kernel<T, D, NW, PAGED, 3>; break;
-        case 4: kern = prefill_fwd_kernel<T, D, NW, PAGED, 4>; break;
-        case 8: kern = prefill_fwd_kernel<T, D, NW, PAGED, 8>; break;
-        case 7: kern = prefill_fwd_kernel<T, D, NW, PAGED, 7>; break;
-        case 15: kern = prefill_fwd_kernel<T, D, NW, PAGED, 15>; break;
-        case 32: kern = prefill_fwd_kernel<T, D, NW, PAGED, 32>; break;
-        case 64: kern = prefill_fwd_kernel<T, D, NW, PAGED, 64>; break;
-        case 66: kern = prefill_fwd_kernel<T, D, NW, PAGED, 66>; break;
-        case 256: kern = prefill_fwd_kernel<T, D, NW, PAGED, 256>; break;
-        case 512: kern = prefill_fwd_kernel<T, D, NW, PAGED, 512>; break;
-        case 1024: kern = prefill_fwd_kernel<T, D, NW, PAGED, 1024>; break;
-        case 2048: kern = prefill_fwd_kernel<T, D, NW, PAGED, 2048>; break;
-        default: break;
-        }
-    }
-#endif
+    auto kern = prefill_fwd_kernel<T, D, NW, PG>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return -3;
@@ -584,7 +579,8 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
 
 template <typename T, int D, int NW>
 static int launch_prefill_t(PrefillArgs& a, hipStream_t stream) {
-    return a.block_table ? launch_prefill_p<T, D, NW, true>(a, stream) : launch_prefill_p<T, D, NW, false>(a, stream);
+    if (!a.block_table) return launch_prefill_p<T, D, NW, 0>(a, stream);
+    return a.page_shift >= 6 ? launch_prefill_p<T, D, NW, 2>(a, stream) : launch_prefill_p<T, D, NW, 1>(a, stream);
 }
 
 template <typename T>
@@ -652,20 +648,21 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
 }
 
 // ---- packed-row kv-cache attention ---------------------------------------------------------------------------
-template <typename T, int D, bool PAGED>
+template <typename T, int D, int PG>
 static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
     constexpr int NW = 4, BM = 32 * NW;
     constexpr int RB = Pitch<D>::RB;
     constexpr size_t smem = 4 * kBN * RB;
     a.mq_rows = a.seqlen_q * a.group;
+    if ((int64_t)a.seqlen_q * std::max(a.q_row_stride, a.o_row_stride) + (int64_t)a.group * std::max(a.q_head_stride, a.o_head_stride) >= (1LL << 31)) return -2;
     a.mq_row_blocks = (a.mq_rows + BM - 1) / BM;
     const int64_t npairs = (int64_t)a.batch * a.kv_heads;
     if (npairs <= 0 || a.mq_rows <= 0) return 0;
     const int64_t total = 8 * ((npairs + 7) / 8) * a.num_splits * a.mq_row_blocks;
     if (total > 0x7fffffffLL) return -1;
-    auto kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true, false>;
+    auto kern = prefill_fwd_kernel<T, D, NW, PG, true, false>;
     static const int env_nt = [] { const char* e = getenv("MFA_MQ_STREAM"); return e ? atoi(e) : -1; }();
-    if (env_nt == 1 || (env_nt != 0 && a.mq_row_blocks == 1)) kern = prefill_fwd_kernel<T, D, NW, PAGED, 0, true, true>;
+    if (env_nt == 1 || (env_nt != 0 && a.mq_row_blocks == 1)) kern = prefill_fwd_kernel<T, D, NW, PG, true, true>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
         return -3;
@@ -675,13 +672,19 @@ static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
 
 template <typename T>
 static int launch_mq_d(PrefillArgs& a, hipStream_t stream) {
-    const bool paged = a.block_table != nullptr;
-    switch (a.head_dim) { // the head dims serving stacks use; others take the per-head prefill path (caller's fallback)
-    case 64: return paged ? launch_mq_p<T, 64, true>(a, stream) : launch_mq_p<T, 64, false>(a, stream);
-    case 128: return paged ? launch_mq_p<T, 128, true>(a, stream) : launch_mq_p<T, 128, false>(a, stream);
-    case 256: return paged ? launch_mq_p<T, 256, true>(a, stream) : launch_mq_p<T, 256, false>(a, stream);
+    const int pg = !a.block_table ? 0 : (a.page_shift >= 6 ? 2 : 1); // (page_shift >= 0: page_size = 2^page_shift)
+#define MFA_MQ_CASE(DD)                                                                                                 \
+    case DD:                                                                                                          \
+        return pg == 0 ? launch_mq_p<T, DD, 0>(a, stream) : pg == 1 ? launch_mq_p<T, DD, 1>(a, stream) : launch_mq_p<T, DD, 2>(a, stream)
+    switch (a.head_dim) { // (160, 192, 224 take the per-head prefill path: the caller's fallback)
+        MFA_MQ_CASE(32);
+        MFA_MQ_CASE(64);
+        MFA_MQ_CASE(96);
+        MFA_MQ_CASE(128);
+        MFA_MQ_CASE(256);
     default: return -2;
     }
+#undef MFA_MQ_CASE
 }
 
 int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream) {

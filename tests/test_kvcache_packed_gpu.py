@@ -68,8 +68,8 @@ def test_few_query_tokens(mfa, Sq, Hq, Hk, causal):
     close(ours, theirs, f"Sq={Sq} {Hq}/{Hk} causal={causal}", lse, lse_ref)
 
 
-@pytest.mark.parametrize("D", [64, 128, 256])
-@pytest.mark.parametrize("page", [16, 64, 256])
+@pytest.mark.parametrize("D", [32, 64, 96, 128, 256])
+@pytest.mark.parametrize("page", [16, 48, 64, 192, 256])
 def test_paged_cache_and_head_dims(mfa, D, page):
     B, Sq, Hq, Hk, Sk = 5, 4, 16, 2, 700
     q = rnd(B, Sq, Hq, D, dtype=torch.bfloat16, seed=7)

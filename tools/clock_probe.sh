@@ -1,8 +1,8 @@
-# effective shader clock of the prefill kernel for two ablation codes: GRBM_GUI_ACTIVE/8/duration
+# effective shader clock of the prefill kernel: GRBM_GUI_ACTIVE/8/duration, for the library as built (to compare ablated
+# builds of the general kernel, rebuild between calls: MFA_EXTRA_HIPCC_FLAGS=-DMFA_DEV_ABL_MASK=<bits>, csrc/mfa_dev.h)
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp; cd /tmp
-for a in ${1:-0 1}; do
-  export MFA_ABLATE=$a
+for a in ${1:-0}; do
   OUT=$ROOT/gpurun_out/clk_$a; mkdir -p $OUT
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/run_shape.py prefill 4096 0 4 > $OUT/log.txt 2>&1
   python3 - $OUT $a <<'PY'

@@ -4,7 +4,7 @@
 SRC=$1; FILTER=${2:-.}
 OUT=/tmp/kres_$$; mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-gpu-rdc -fno-math-errno -mllvm -amdgpu-early-inline-all=true \
-   --cuda-device-only -S "$SRC" -o $OUT/k.s || exit 1
+   -I "$(dirname "$SRC")" --cuda-device-only -S "$SRC" -o $OUT/k.s 2>$OUT/err.txt || { cat $OUT/err.txt; exit 1; }
 python3 - "$OUT/k.s" "$FILTER" <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read(); flt=sys.argv[2]

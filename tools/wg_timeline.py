@@ -1,7 +1,9 @@
-"""Phase timeline of the prefill workgroups (developer tool; needs the MFA_ABLATION=1 build and MFA_ABLATE=1024).
+"""Phase timeline of the workgroups of the general prefill kernel (prefill_fwd_kernel; developer tool, needs a build
+with the stamps of csrc/mfa_dev.h compiled in; the 64-rows-per-wave kernel has tools/p64_timeline.py):
 
-    MFA_ABLATION=1 python mini-flash-attention_amd/build.py
-    MFA_ABLATE=1024 python tools/wg_timeline.py [S] [causal]
+    MFA_EXTRA_HIPCC_FLAGS=-DMFA_DEV_TIMELINE python mini-flash-attention_amd/build.py
+    MFA_PREFILL64=0 python tools/wg_timeline.py [S] [causal]
+    python mini-flash-attention_amd/build.py        # back to the product build
 
 The instrumented kernel variant writes, per workgroup, four 100 MHz timestamps (entry, prologue done = Q + first
 K/V tile landed, tile loop done, output stores issued) plus HW_ID / XCC_ID into the LSE buffer.  This script turns
