@@ -436,6 +436,7 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
         if (gt == 7) gt = 8;
     }
     a.nchunks = (G + gt - 1) / gt;
+    if (a.batch > 65535 || (int64_t)a.kv_heads * a.nchunks > 65535) return -4; // grid.z / grid.y limits
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
 }
 

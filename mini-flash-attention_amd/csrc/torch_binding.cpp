@@ -8,6 +8,7 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
+#include <algorithm>
 #include <optional>
 #include <tuple>
 
@@ -16,6 +17,9 @@
 namespace {
 
 #define MFA_CHECK_DEVICE(x) TORCH_CHECK(x.is_cuda(), #x " must be on CUDA")
+// every tensor argument must live on q's device: the kernels run on q's device and stream with raw pointers
+#define MFA_CHECK_SAME_DEVICE(x, ref) \
+    TORCH_CHECK(x.is_cuda() && x.device() == ref.device(), #x " must be on the same device as " #ref)
 #define MFA_CHECK_SHAPE(x, ...) \
     TORCH_CHECK(x.sizes() == at::IntArrayRef({__VA_ARGS__}), #x " must have shape (" #__VA_ARGS__ ")")
 
@@ -31,8 +35,8 @@ void check_dtypes(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v)
     TORCH_CHECK(k.scalar_type() == dtype, "query and key must have the same dtype");
     TORCH_CHECK(v.scalar_type() == dtype, "query and value must have the same dtype");
     MFA_CHECK_DEVICE(q);
-    MFA_CHECK_DEVICE(k);
-    MFA_CHECK_DEVICE(v);
+    MFA_CHECK_SAME_DEVICE(k, q);
+    MFA_CHECK_SAME_DEVICE(v, q);
     TORCH_CHECK(q.stride(-1) == 1, "Input tensor must have contiguous last dimension");
     TORCH_CHECK(k.stride(-1) == 1, "Input tensor must have contiguous last dimension");
     TORCH_CHECK(v.stride(-1) == 1, "Input tensor must have contiguous last dimension");
@@ -73,7 +77,7 @@ void set_windows(mfa_forward_params& p, int wl, int wr, int seqlen_k) {
 
 void set_paged(mfa_forward_params& p, const at::Tensor& block_table, const at::Tensor& k, const at::Tensor& v,
                int batch) {
-    MFA_CHECK_DEVICE(block_table);
+    MFA_CHECK_SAME_DEVICE(block_table, k);
     TORCH_CHECK(block_table.scalar_type() == at::kInt, "block_table must be int32");
     TORCH_CHECK(block_table.dim() == 2 && block_table.size(0) == batch,
                 "block_table must have the same batch size as q");
@@ -132,7 +136,7 @@ at::Tensor flash_attention_forward(const at::Tensor& q, const at::Tensor& k, con
     if (out_.has_value()) {
         out = out_.value();
         TORCH_CHECK(out.scalar_type() == q.scalar_type(), "Output tensor must have the dtype of q");
-        MFA_CHECK_DEVICE(out);
+        MFA_CHECK_SAME_DEVICE(out, q);
         TORCH_CHECK(out.stride(-1) == 1, "Output tensor must have contiguous last dimension");
         MFA_CHECK_SHAPE(out, batch, seqlen_q, num_heads, head_dim);
     } else {
@@ -161,8 +165,8 @@ at::Tensor flash_attention_varlen_forward(const at::Tensor& q, const at::Tensor&
                                           const std::optional<at::Tensor>& block_table_) {
     check_dtypes(q, k, v);
     c10::DeviceGuard guard(q.device());
-    MFA_CHECK_DEVICE(cu_seqlens_q);
-    MFA_CHECK_DEVICE(cu_seqlens_k);
+    MFA_CHECK_SAME_DEVICE(cu_seqlens_q, q);
+    MFA_CHECK_SAME_DEVICE(cu_seqlens_k, q);
     TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_k.scalar_type() == at::kInt,
                 "cu_seqlens_q and cu_seqlens_k must be int32");
     TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens must be contiguous");
@@ -204,6 +208,11 @@ at::Tensor flash_attention_varlen_forward(const at::Tensor& q, const at::Tensor&
         const int total_k = k.size(0);
         MFA_CHECK_SHAPE(k, total_k, kv_num_heads, head_dim);
         MFA_CHECK_SHAPE(v, total_k, kv_num_heads, head_dim);
+        // K/V rows are addressed with 32-bit byte offsets from each sequence's first row; the library checks that with
+        // max_seqlen_k, which the caller could under-report: bound the span with the tensor itself.  (max_seqlen_q /
+        // max_seqlen_k must be >= the longest sequence in cu_seqlens: rows past an under-reported maximum are not computed.)
+        TORCH_CHECK(static_cast<int64_t>(total_k) * std::max(k.stride(0), v.stride(0)) * 2 < (1LL << 32),
+                    "varlen k/v span 4 GiB or more: split the batch or use a paged cache");
     }
     check_rc(mfa_run_flash_attention_forward(&p, current_stream(q)));
     return out;
@@ -254,7 +263,7 @@ at::Tensor mha_fwd_kvcache(const at::Tensor& q, const at::Tensor& k_cache, const
 
     if (seqlens_k_.has_value()) {
         const auto& seqlens_k = seqlens_k_.value();
-        MFA_CHECK_DEVICE(seqlens_k);
+        MFA_CHECK_SAME_DEVICE(seqlens_k, q);
         TORCH_CHECK(seqlens_k.scalar_type() == at::kInt, "seqlens_k must be int32");
         TORCH_CHECK(seqlens_k.numel() == batch, "seqlens_k must have the same number of elements as batch size");
         TORCH_CHECK(seqlens_k.is_contiguous(), "seqlens_k must be contiguous");
@@ -305,7 +314,7 @@ OutLse forward_ex(const at::Tensor& q, const at::Tensor& k, const at::Tensor& v,
     at::Tensor out;
     if (out_.has_value()) {
         out = out_.value();
-        TORCH_CHECK(out.scalar_type() == q.scalar_type() && out.is_cuda() && out.stride(-1) == 1, "bad out tensor");
+        TORCH_CHECK(out.scalar_type() == q.scalar_type() && out.is_cuda() && out.device() == q.device() && out.stride(-1) == 1, "bad out tensor");
         MFA_CHECK_SHAPE(out, batch, seqlen_q, num_heads, head_dim);
     } else {
         out = at::empty_like(q);
@@ -332,8 +341,8 @@ OutLse varlen_forward_ex(const at::Tensor& q, const at::Tensor& k, const at::Ten
                          const std::optional<at::Tensor>& block_table_) {
     check_dtypes(q, k, v);
     c10::DeviceGuard guard(q.device());
-    MFA_CHECK_DEVICE(cu_seqlens_q);
-    MFA_CHECK_DEVICE(cu_seqlens_k);
+    MFA_CHECK_SAME_DEVICE(cu_seqlens_q, q);
+    MFA_CHECK_SAME_DEVICE(cu_seqlens_k, q);
     TORCH_CHECK(cu_seqlens_q.scalar_type() == at::kInt && cu_seqlens_k.scalar_type() == at::kInt,
                 "cu_seqlens_q and cu_seqlens_k must be int32");
     TORCH_CHECK(cu_seqlens_q.is_contiguous() && cu_seqlens_k.is_contiguous(), "cu_seqlens must be contiguous");
@@ -365,6 +374,8 @@ OutLse varlen_forward_ex(const at::Tensor& q, const at::Tensor& k, const at::Ten
         TORCH_CHECK(k.dim() == 3 && v.dim() == 3, "k, v must be (total_k, heads_k, head_dim)");
         MFA_CHECK_SHAPE(k, k.size(0), kv_num_heads, head_dim);
         MFA_CHECK_SHAPE(v, k.size(0), kv_num_heads, head_dim);
+        TORCH_CHECK(static_cast<int64_t>(k.size(0)) * std::max(k.stride(0), v.stride(0)) * 2 < (1LL << 32),
+                    "varlen k/v span 4 GiB or more: split the batch or use a paged cache");
     }
     std::optional<at::Tensor> lse;
     if (return_lse) {
@@ -407,7 +418,7 @@ OutLse kvcache_ex(const at::Tensor& q, const at::Tensor& k_cache, const at::Tens
     const int32_t* seqlens_ptr = nullptr;
     if (seqlens_k_.has_value()) {
         const auto& seqlens_k = seqlens_k_.value();
-        MFA_CHECK_DEVICE(seqlens_k);
+        MFA_CHECK_SAME_DEVICE(seqlens_k, q);
         TORCH_CHECK(seqlens_k.scalar_type() == at::kInt && seqlens_k.numel() == batch && seqlens_k.is_contiguous(),
                     "seqlens_k must be a contiguous int32 tensor with one element per batch entry");
         seqlens_ptr = seqlens_k.data_ptr<int>();
@@ -419,8 +430,8 @@ OutLse kvcache_ex(const at::Tensor& q, const at::Tensor& k_cache, const at::Tens
         TORCH_CHECK(seqlens_ptr != nullptr, "cache_seqlens is required when appending k, v");
         const auto &kn = k_new_.value(), &vn = v_new_.value();
         TORCH_CHECK(kn.scalar_type() == q.scalar_type() && vn.scalar_type() == q.scalar_type(), "k, v dtype must match q");
-        MFA_CHECK_DEVICE(kn);
-        MFA_CHECK_DEVICE(vn);
+        MFA_CHECK_SAME_DEVICE(kn, q);
+        MFA_CHECK_SAME_DEVICE(vn, q);
         TORCH_CHECK(kn.dim() == 4 && kn.stride(-1) == 1 && vn.stride(-1) == 1, "k, v must be (batch, seqlen_new, heads_k, head_dim)");
         appended = kn.size(1);
         MFA_CHECK_SHAPE(kn, batch, appended, kv_num_heads, head_dim);
