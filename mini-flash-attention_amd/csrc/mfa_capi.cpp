@@ -202,9 +202,12 @@ static int kvcache_route(const mfa_forward_params* p) {
     const int g = p->kv_heads > 0 ? p->heads / p->kv_heads : 1;
     const bool has_packed = p->head_dim == 32 || p->head_dim == 64 || p->head_dim == 96 || p->head_dim == 128 || p->head_dim == 256;
     const int64_t rows = static_cast<int64_t>(p->seqlen_q) * g;
-    // (paged caches: the vector kernel resolves a page per key on the VALU and drops to 4.5-4.9 TB/s for groups of 3-4;
-    //  the packed kernel's row-gather DMA holds 5.3-5.6: profiles/r01d_kvcache_paged_routes.txt)
-    const bool paged_group = p->block_table != nullptr && g >= 3;
+    // (paged caches, groups of 3-4: the packed kernel's tile DMA holds 5.3-5.6 TB/s where the vector kernel does 4.8
+    //  (profiles/r01d_kvcache_paged_routes.txt, r02 re-measured with the vector kernel's page-aligned mode: 4.76 vs
+    //  5.29 on BASELINE config 5) -- but only when a 64-key tile lies in one page; with smaller or odd page sizes the
+    //  packed kernel looks a page up per staged row and falls to 3.0 TB/s, the vector kernel keeps 5.1)
+    const int ps = p->page_block_size;
+    const bool paged_group = p->block_table != nullptr && g >= 3 && ps >= 64 && (ps & (ps - 1)) == 0;
     bool packed = has_packed && rows <= 512 && (p->seqlen_q > 1 || g > 4 || p->use_local_window || paged_group);
     if (env == 0) packed = false;
     if (env == 1 && has_packed) packed = true;

@@ -65,7 +65,11 @@ struct RowBuf {
     u32x4 r[N];
 };
 
-enum { kDense = 0, kPagedPow2 = 1, kPagedDiv = 2 };
+// kPagedAligned: page_size is a power of two and a multiple of the workgroup iteration (TILE keys, TILE <= 64): a whole
+// iteration lies in one page, so the page is ONE scalar block-table load per iteration and the rows are addressed as in
+// the dense case, 32-bit lane offsets on a wave-uniform base (the reference resolves a page per 64-key tile the same way,
+// decode.cuh:50-55); the other paged modes look a page up per key on the VALU.
+enum { kDense = 0, kPagedPow2 = 1, kPagedDiv = 2, kPagedAligned = 3 };
 
 template <typename T, int LPR, int GT, int MODE>
 __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const DecodeArgs a) {
@@ -125,22 +129,33 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     // Loads never branch: a key past the end of this split is clamped to its last key (a valid, finite row whose
     // score is masked to -inf below), so over-running iterations only re-read one cached row.
     // page id for the clamped key (paged), looked up one iteration ahead of the row loads that need it
-    auto page_lookup = [&](int key) -> int {
+    auto page_lookup = [&](int key, int u = 0) -> int {
         if constexpr (!paged) return 0;
+        if constexpr (MODE == kPagedAligned) { // one page per iteration (the same for every lane): slot 0 carries it
+            if (u != 0) return 0;
+            return __builtin_amdgcn_readfirstlane(table[min(min(key, kend - 1) >> a.page_shift, a.max_blocks - 1)]);
+        }
         key = min(key, kend - 1);
         const int pg = MODE == kPagedPow2 ? (key >> a.page_shift) : (key / a.page_size);
         return table[min(pg, a.max_blocks - 1)];
     };
     auto load_rows = [&](RowBuf<kUnroll>& kb, RowBuf<kUnroll>& vb, int k0, const int (&pid)[kUnroll]) {
+        const char *kpage = kbase, *vpage = vbase;
+        if constexpr (MODE == kPagedAligned) {
+            const int64_t pb = pid[0]; // looked up one iteration ahead
+            kpage = kbase + 2 * pb * a.k_block_stride;
+            vpage = vbase + 2 * pb * a.v_block_stride;
+        }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int key = min(key_of(k0, u), kend - 1);
-            if constexpr (!paged) {
-                // 32-bit byte offsets on a wave-uniform base (one (batch, kv head) slab is < 4 GiB)
-                const uint32_t ko = (uint32_t)key * (uint32_t)(2 * a.k_row_stride) + 16 * cc;
-                const uint32_t vo = (uint32_t)key * (uint32_t)(2 * a.v_row_stride) + 16 * cc;
-                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kbase + ko));
-                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vbase + vo));
+            if constexpr (!paged || MODE == kPagedAligned) {
+                // 32-bit byte offsets on a wave-uniform base (one (batch, kv head) slab, or one page, is < 4 GiB)
+                const uint32_t row = MODE == kPagedAligned ? (uint32_t)(key & (a.page_size - 1)) : (uint32_t)key;
+                const uint32_t ko = row * (uint32_t)(2 * a.k_row_stride) + 16 * cc;
+                const uint32_t vo = row * (uint32_t)(2 * a.v_row_stride) + 16 * cc;
+                kb.r[u] = __builtin_nontemporal_load((const u32x4*)(kpage + ko));
+                vb.r[u] = __builtin_nontemporal_load((const u32x4*)(vpage + vo));
             } else {
                 const int in = MODE == kPagedPow2 ? (key & (a.page_size - 1)) : (key % a.page_size);
                 const int64_t ko = (int64_t)pid[u] * a.k_block_stride + (int64_t)in * a.k_row_stride;
@@ -202,23 +217,23 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
         RowBuf<kUnroll> kA, vA, kB, vB;
         int pid[kUnroll], pidn[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg, u));
+        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg, u), u);
         load_rows(kA, vA, kbeg, pid);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg + TILE, u));
+        for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(kbeg + TILE, u), u);
         // sched_barrier: without it hipcc's scheduler, chasing occupancy, sinks every load down to its first use
         // (load; s_waitcnt vmcnt(0); use), which serialises the whole stream.  The loads of the NEXT buffer must
         // issue before the compute on the CURRENT one.
         for (int k0 = kbeg; k0 < kend; k0 += 2 * TILE) {
             load_rows(kB, vB, k0 + TILE, pid);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) pidn[u] = page_lookup(key_of(k0 + 2 * TILE, u));
+            for (int u = 0; u < kUnroll; ++u) pidn[u] = page_lookup(key_of(k0 + 2 * TILE, u), u);
             __builtin_amdgcn_sched_barrier(0);
             compute(kA, vA, k0);
             __builtin_amdgcn_sched_barrier(0);
             load_rows(kA, vA, k0 + 2 * TILE, pidn);
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(k0 + 3 * TILE, u));
+            for (int u = 0; u < kUnroll; ++u) pid[u] = page_lookup(key_of(k0 + 3 * TILE, u), u);
             __builtin_amdgcn_sched_barrier(0);
             compute(kB, vB, k0 + TILE);
             __builtin_amdgcn_sched_barrier(0);
@@ -371,6 +386,8 @@ static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
     const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
     if (!a.block_table)
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kDense>), grid, dim3(kDecodeThreads), smem, stream, a);
+    else if (a.page_shift >= 0 && LPR >= 16 && a.page_size >= kDecodeWaves * kUnroll * (64 / LPR))
+        hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedAligned>), grid, dim3(kDecodeThreads), smem, stream, a);
     else if (a.page_shift >= 0)
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedPow2>), grid, dim3(kDecodeThreads), smem, stream, a);
     else

@@ -61,6 +61,8 @@ Blocks (P = parity of a tile's S buffer, C = chain); scalar operands are named i
                         (status 1, tile j's phases done, its sums not yet accepted)
     P64_X{P}_SM         phase X alone: scores of the K tile in slot %[kslot] into buffer P, softmax steps 32..63 of buffer P^1
     P64_Y{P}[_SM]       phase Y alone: O += V.P, P in buffer P, V tile in slot %[vslot] [softmax steps 0..31 of buffer P^1]
+    P64_LAST{P}[_M]     a wave's last tile (scores in buffer P) in one piece: phase Y of the tile before with the first half
+                        of its softmax, the second half, the test of the sums; _M: its mask applied on the way
     P64_SM2_{P}         softmax steps 32..63 of buffer P with nothing to hide under
     P64_MASK{P}         key > row + hi or key >= sk -> -inf on both chains of buffer P
     P64_CHECK           test of the two tile sums; passing chains: l += lt; status bit c = chain c failed
@@ -177,10 +179,14 @@ class Stream:
     # ---- softmax of one tile as 64 element steps u (u & 1: chain, u >> 1: element 16*kb + i): fma + exp in place now,
     # the row-sum add one element later (the first add of a tile writes lt = x0 + x1), the pack of a finished pair (in
     # place, word i/2) right behind its second add
-    def sm_step(self, P, u):
+    def sm_step(self, P, u, masked=False):
         if "sm" in self.ablate or ("smx" in self.ablate and u >= 32) or ("smy" in self.ablate and u < 32):
             return
         ch, e = u & 1, u >> 1
+        if masked:  # (last_block) key > row + hi or key >= sk -> -inf, ahead of the element's fma
+            k = 32 * (e >> 4) + ((e & 15) & 3) + 8 * ((e & 15) >> 2)
+            self.e(f"v_cmp_gt_i32 vcc, {k}, {vr(TMP(ch, 0))}")
+            self.e(f"v_cndmask_b32 {vr(S_BASE(P, ch) + e)}, {vr(S_BASE(P, ch) + e)}, {vr(TMP(0, 1))}, vcc")
 
         x = vr(S_BASE(P, ch) + e)
         self.e(f"v_fma_f32 {x}, {x}, %[c], {vr(MC(ch))}")  # (issuing the fma a step ahead of its exp: measured, no gain)
@@ -425,6 +431,43 @@ class Stream:
                 self.v_read_half(f + PF, ch)
         for d in range(4):
             self.e(f"v_subrev_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
+        self.pads()
+        return self.out
+
+    def last_block(self, P, masked):
+        """a wave's LAST tile j (scores in buffer P) in one piece: phase Y of tile j-1 (V tile in slot %[vslot]) with the
+        first half of tile j's softmax in its gaps, the second half behind it (no next tile: nothing to hide under), the
+        test of the tile sums (status as P64_CHECK).  masked: the tile's mask (key > row + hi or key >= sk -> -inf;
+        %[skm1], %[j64]) applied element by element just ahead of the softmax -- the causal diagonal tile, or the ragged
+        last one."""
+        self.lds_log = []
+        self.pads()
+        for d in range(4):
+            self.e(f"v_add_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
+        for f in range(PF):
+            self.v_read(f)
+        if masked:
+            for ch in range(2):
+                t0 = TMP(ch, 0)
+                self.e(f"v_min_i32 {vr(t0)}, %[skm1], {vr(QHI(ch))}")
+                self.e(f"v_subrev_u32 {vr(t0)}, %[j64], {vr(t0)}")
+                self.e(f"v_sub_u32 {vr(t0)}, {vr(t0)}, {vr(H4)}")  # keys at tile offsets <= t0 stay
+            self.e(f"v_mov_b32 {vr(TMP(0, 1))}, 0x{NEG_INF:x}")
+        self.wait_frag("V", 0, 0, pad=True)
+        for t in range(32):
+            ch, f = t & 1, t >> 1
+            self.mfma_y(P ^ 1, t)
+            if ch == 1 and f < 15:
+                self.wait_frag("V", 0, f + 1)
+            self.sm_step(P, t, masked)
+            if f + PF <= 15:
+                self.v_read_half(f + PF, ch)
+        for d in range(4):
+            self.e(f"v_subrev_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
+        for u in range(32, 64):
+            self.sm_step(P, u, masked)
+        self.sm_tail(P)
+        self.check_block()
         self.pads()
         return self.out
 
@@ -732,6 +775,9 @@ def main():
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
             emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [], [VS, C_OP])
+            emit_block(fh, f"P64_LAST{pn}", lambda st, pn=pn: st.last_block(pn, False), ['[status] "=&s"(status)'], [VS, C_OP])
+            emit_block(fh, f"P64_LAST{pn}_M", lambda st, pn=pn: st.last_block(pn, True), ['[status] "=&s"(status)'],
+                       [VS, C_OP, '[skm1] "s"(skm1)', '[j64] "s"(j64)'])
             emit_block(fh, f"P64_SM2_{pn}", lambda st, pn=pn: st.sm_second_half(pn), [], [C_OP])
             emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], ['[skm1] "s"(skm1)', '[j64] "s"(j64)'])
             for ch in range(2):
