@@ -464,12 +464,45 @@ class Stream:
                 self.v_read_half(f + PF, ch)
         for d in range(4):
             self.e(f"v_subrev_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
-        for u in range(32, 64):
-            self.sm_step(P, u, masked)
-        self.sm_tail(P)
+        self.sm_batched(P, 32, 64, masked)
         self.check_block()
         self.pads()
         return self.out
+
+    def sm_batched(self, P, u0, u1, masked=False):
+        """softmax steps u0..u1-1 of buffer P (u0 > 0, even) with no MFMAs to ride under: the same instructions as sm_step
+        would issue, in batches of eight elements stage by stage -- mask, fma, exp, then the row-sum adds and packs of the
+        batch BEFORE -- so that no instruction waits for the result of the one just ahead of it (a dependent VALU pair
+        issued back to back costs the wave about twice the issue slot)"""
+        B = 8
+        batches = [list(range(b0, min(b0 + B, u1))) for b0 in range(u0, u1, B)]
+
+        def sums(us):  # sm_step(u) sums element e-1 = the element of step u-2: after a batch's exps, sum ITS elements
+            for u in us:
+                self.sm_sum(P, u & 1, u >> 1)
+
+        # (step u0's sm_step would first sum element (u0 >> 1) - 1, whose exp ran in the phase before: do those two now)
+        for u in (u0 - 2, u0 - 1):
+            self.sm_sum(P, u & 1, u >> 1)
+        prev = None
+        for us in batches:
+            if masked:
+                for u in us:
+                    ch, e = u & 1, u >> 1
+                    k = 32 * (e >> 4) + ((e & 15) & 3) + 8 * ((e & 15) >> 2)
+                    x = vr(S_BASE(P, ch) + e)
+                    self.e(f"v_cmp_gt_i32 vcc, {k}, {vr(TMP(ch, 0))}")
+                    self.e(f"v_cndmask_b32 {x}, {x}, {vr(TMP(0, 1))}, vcc")
+            for u in us:
+                x = vr(S_BASE(P, u & 1) + (u >> 1))
+                self.e(f"v_fma_f32 {x}, {x}, %[c], {vr(MC(u & 1))}")
+            for u in us:
+                x = vr(S_BASE(P, u & 1) + (u >> 1))
+                self.e(f"v_exp_f32 {x}, {x}")
+            if prev:
+                sums(prev)
+            prev = us
+        sums(prev)
 
     def sm_second_half(self, P):
         self.pads()
