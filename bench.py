@@ -9,12 +9,13 @@ A "step" is one pass of the hot path over one batch of synthetic input, already 
     FLOPs = 4*B*H*S^2*D / 2);
   * "decode" object: BASELINE config 3 — bf16 B=24 Sq=1 Skv=8192 Hq=24 Hkv=8 D=128, num_splits auto, timed the
     same way right after, reported as HBM GB/s of the algorithmic bytes (K+V once per KV head, + Q + O).
-Beside the contract's timed region (N=1 only, outside it): "sweep" — the reference benchmark's prefill shape family
+Beside the contract's timed regions (outside them, and BEFORE them): "sweep" — the reference benchmark's prefill shape family
 (fp16 B=48 H=24 D=128, S = 256 .. 4096, causal and not), and "decode_sweep" — the reference README's MHA fp16
 decode shapes (B=24 H=24 Skv = 512 .. 8192) and BASELINE config 5 (paged), each over ROTATING cache copies so no
 launch finds its cache in the 256 MB Infinity Cache.  Every sweep entry carries two regimes: "cold" = the first 25
-launches after an idle gap (what a short driver run sees: clocks and power have not settled) and "steady" = after
-about half a second of back-to-back launches.
+launches after an idle gap (clocks and power have not settled: a 25-launch run from idle measures the ramp, not the
+kernel) and "steady" = after about half a second of back-to-back launches.  Because the sweeps run first, the headline /
+decode / kvcache_packed regions start at settled clocks whatever --steps / --warmup are.
 Multi-GPU: the path is embarrassingly parallel over batch x heads and has no exchange step ("replicas only",
 DESIGN.md): every rank runs its own batch (weak scaling), the timed region is bracketed by barrier +
 synchronize, elapsed = MAX over ranks, value = all ranks' work / that time.
@@ -239,6 +240,16 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     torch.manual_seed(rank)
+    # The sweeps run FIRST (every rank runs its own): they carry both regimes per shape, and they leave the GPU at settled
+    # clocks, so the contract's timed regions below (W warm-up + K timed steps each) measure the kernels rather than the
+    # power-state ramp of the first ~30 ms after an idle period -- which `sweep[*].cold` reports, shape by shape.
+    sweeps = {}
+    if not args.no_sweep:
+        sweeps["sweep"] = prefill_sweep(mfa, dev)
+        sweeps["decode_sweep"] = decode_sweep(mfa, dev)
+        sweeps["regimes"] = ("cold = mean of the first 25 launches after a 0.25 s idle gap; steady = mean of 4-40 launches "
+                             "after >= 0.3-0.5 s of back-to-back launches; HIP events on the launch stream; the headline, decode "
+                             "and kvcache_packed regions run after the sweeps (settled clocks)")
     c = PREFILL
     q = torch.randn(c["B"], c["S"], c["H"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"])
     k = torch.randn(c["B"], c["S"], c["Hk"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"])
@@ -301,13 +312,6 @@ def main():
                      "algorithmic_bytes": decode_bytes(g8)},
     }
     del qg, kc, vc
-
-    sweeps = {}
-    if n_gpus == 1 and not dist and not args.no_sweep:  # outside the timed regions; a few seconds each
-        sweeps["sweep"] = prefill_sweep(mfa, dev)
-        sweeps["decode_sweep"] = decode_sweep(mfa, dev)
-        sweeps["regimes"] = ("cold = mean of the first 25 launches after a 0.25 s idle gap; steady = mean of 4-40 launches "
-                             "after >= 0.3-0.5 s of back-to-back launches; HIP events on the launch stream")
 
     if rank == 0:
         out = {
