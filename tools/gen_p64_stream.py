@@ -453,13 +453,32 @@ class Stream:
                 self.e(f"v_subrev_u32 {vr(t0)}, %[j64], {vr(t0)}")
                 self.e(f"v_sub_u32 {vr(t0)}, {vr(t0)}, {vr(H4)}")  # keys at tile offsets <= t0 stay
             self.e(f"v_mov_b32 {vr(TMP(0, 1))}, 0x{NEG_INF:x}")
+        def mask_ops(u):  # (compare, select) of step u's element
+            ch, e = u & 1, u >> 1
+            k = 32 * (e >> 4) + ((e & 15) & 3) + 8 * ((e & 15) >> 2)
+            x = vr(S_BASE(P, ch) + e)
+            return f"v_cmp_gt_i32 vcc, {k}, {vr(TMP(ch, 0))}", f"v_cndmask_b32 {x}, {x}, {vr(TMP(0, 1))}, vcc"
+
+        if masked:
+            self.out += mask_ops(0)
         self.wait_frag("V", 0, 0, pad=True)
         for t in range(32):
             ch, f = t & 1, t >> 1
             self.mfma_y(P ^ 1, t)
             if ch == 1 and f < 15:
                 self.wait_frag("V", 0, f + 1)
-            self.sm_step(P, t, masked)
+            # the element's mask one gap ahead, interleaved with this gap's fma / exp: no instruction directly behind the
+            # one whose result it needs
+            nxt = mask_ops(t + 1) if masked and t + 1 < 32 else None
+            x = vr(S_BASE(P, ch) + (t >> 1))
+            if nxt:
+                self.e(nxt[0])
+            self.e(f"v_fma_f32 {x}, {x}, %[c], {vr(MC(ch))}")
+            if nxt:
+                self.e(nxt[1])
+            self.e(f"v_exp_f32 {x}, {x}")
+            if t >= 2:
+                self.sm_sum(P, ch, (t >> 1) - 1)
             if f + PF <= 15:
                 self.v_read_half(f + PF, ch)
         for d in range(4):

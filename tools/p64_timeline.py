@@ -43,6 +43,6 @@ m = nt == nt.max()
 for i in range(1, -1, -1):
     a = (d[m, 9 + 2 * i] - d[m, 8 + 2 * i]).float(); b = ((d[m, 8 + 2 * (i - 1)] if i else d[m, 5]) - d[m, 9 + 2 * i]).float()
     print(f"  iteration nt-{i}: barrier wait {a.mean().item():7.0f}  body {b.mean().item():7.0f}")
-for a, b, nm in ((12, 13, "decode + context"), (13, 14, "K0' K1' V0' DMA issue"), (14, 15, "Q' DMA issue")):
+for a, b, nm in ((13, 14, "K0' K1' V0' DMA issue"), (14, 15, "Q' DMA issue")):
     x = (d[m, b] - d[m, a]).float()
     print(f"  prefetch {nm:24s} {x.mean().item():7.0f}")
