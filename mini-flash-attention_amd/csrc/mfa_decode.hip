@@ -19,6 +19,7 @@
 
 #include "mfa_device.h"
 #include "mfa_launch.h"
+#include "mfa_combine.h"
 
 namespace mfa {
 
@@ -311,73 +312,23 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     }
 }
 
-// O = sum_s o_s * exp(lse_s - LSE), LSE = ln sum_s exp(lse_s)  (decode.cuh:718-747, max-subtracted).
-// One WAVE per (batch, query position, head) row, four rows per workgroup: the split weights stay in two registers
-// per lane (S <= 128), every reduction is a wave shuffle (no LDS, no barrier), and a lane owns column pairs
-// (2*lane, 2*lane+1) + 128*k of the row, so the partial-O reads are 8-byte coalesced and all splits' loads of a
-// column pair are independent.  (The first version used a workgroup per row with four barriers: 6.0 us for 1 536
+// The split merge as its own launch: one WAVE per (batch, query position, head) row, four rows per workgroup
+// (combine_row, mfa_combine.h).  (The first version used a workgroup per row with four barriers: 6.0 us for 1 536
 // rows x 8 splits; this one 3 us.)
 constexpr int kCombineRows = 4;
 template <typename T>
 __global__ __launch_bounds__(64 * kCombineRows) void decode_combine_kernel(const DecodeArgs a) {
-    const int D = a.head_dim, S = a.num_splits;
     const int64_t BH = (int64_t)a.batch * a.seqlen_q * a.heads;
     const int lane = threadIdx.x & 63;
     const int64_t bh = (int64_t)blockIdx.x * kCombineRows + (threadIdx.x >> 6);
     if (bh >= BH) return; // whole wave
-    const float l0 = lane < S ? a.lse_acc[lane * BH + bh] : -INFINITY;
-    const float l1 = lane + 64 < S ? a.lse_acc[(lane + 64) * BH + bh] : -INFINITY;
-    // the first chunk of partial-O loads does not depend on the weights: issue it behind the LSE loads so that the
-    // kernel pays one memory round trip, not two (it is latency, not bandwidth, that this kernel consists of)
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    constexpr int CH = 8;
-    const int d0 = 2 * lane;
-    const float* src0 = a.o_acc + bh * D + d0;
-    f32x2 first[CH];
-#pragma unroll
-    for (int u = 0; u < CH; ++u)
-        first[u] = (u < S && d0 < D) ? *(const f32x2*)(src0 + (int64_t)u * BH * D) : f32x2{0.f, 0.f};
-    float M = fmaxf(l0, l1);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
-    const float w0 = (lane < S && M != -INFINITY) ? __expf(l0 - M) : 0.f;
-    const float w1 = (lane + 64 < S && M != -INFINITY) ? __expf(l1 - M) : 0.f;
-    float W = w0 + w1;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) W += __shfl_xor(W, off);
-    const float invW = W > 0.f ? 1.f / W : 0.f;
     const int h = bh % a.heads;
     const int64_t t = bh / a.heads;
     const int pos = t % a.seqlen_q;
     const int64_t b = t / a.seqlen_q;
     char* orow = (char*)a.o + 2 * (b * a.o_batch_stride + pos * a.o_row_stride + (int64_t)h * a.o_head_stride);
-    // Every lane walks the column loop (the trip count is wave-uniform); only the loads and the store are
-    // predicated on d < D.  The split weights travel by v_readlane, which ignores EXEC: a ds_bpermute broadcast
-    // under the `d < D` guard returned 0 for weights held by lanes with 2*lane >= D (head dims < 128, splits >= D/2).
-    for (int dd = 0; dd < D; dd += 128) { // D is a multiple of 8: pairs never straddle the row end
-        const int d = dd + d0;
-        const bool col = d < D;
-        f32x2 acc = {0.f, 0.f};
-        const float* src = a.o_acc + bh * D + d;
-        for (int s0 = 0; s0 < S; s0 += CH) {
-            f32x2 v[CH];
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                if (dd == 0 && s0 == 0) v[u] = first[u];
-                else v[u] = (col && s0 + u < S) ? *(const f32x2*)(src + (int64_t)(s0 + u) * BH * D) : f32x2{0.f, 0.f};
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int sp = s0 + u; // wave-uniform; weights of splits >= S are 0
-                const float w = __builtin_bit_cast(
-                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sp < 64 ? w0 : w1), sp & 63));
-                acc += w * v[u];
-            }
-        }
-        if (col) *(uint32_t*)(orow + 2 * d) = Elem<T>::pack(acc[0] * invW, acc[1] * invW);
-    }
-    if (lane == 0 && a.lse) // (B, H, Sq)
-        a.lse[(b * a.heads + h) * a.seqlen_q + pos] = (M != -INFINITY) ? M + __logf(W) : -INFINITY;
+    float* lse_out = a.lse ? a.lse + (b * a.heads + h) * a.seqlen_q + pos : nullptr; // (B, H, Sq)
+    combine_row<T>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, a.head_dim, orow, lse_out, lane);
 }
 
 template <typename T, int LPR, int GT>

@@ -19,11 +19,15 @@
 //   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
 //     run on one XCD (shared L2), heaviest causal blocks first.
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <cstdlib>
 #include <type_traits>
 
 #include "mfa_device.h"
 #include "mfa_launch.h"
+#include "mfa_combine.h"
 #include "mfa_dev.h"
 #include "mfa_prefill_args.h"
 
@@ -510,6 +514,27 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
                         *(f32x4*)(op + 32 * d + 8 * g4) = w;
                     }
             }
+            if (!a.split_ctr) return; // the caller merges the partials (decode_combine_kernel)
+            // The last key split of this row block to arrive merges them here: partials released (agent scope), one
+            // arrival ticket per workgroup, the winner acquires, resets the counter for the next launch and runs one wave
+            // per row over the block's rows.  (All splits of a (batch, KV head) run on one XCD: the partials sit in its L2.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's partial stores are in the XCD's L2
+            __syncthreads();
+            int* const flag = (int*)smem; // (the K/V buffers are free: the loop's last barrier)
+            const int ctr_idx = (b * a.kv_heads + hk) * a.mq_row_blocks + m0 / BM;
+            if (tid == 0) *flag = atomicAdd(a.split_ctr + ctr_idx, 1);
+            __syncthreads();
+            if (*flag != a.num_splits - 1) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's L1 lines of the partial buffers
+            if (tid == 0) a.split_ctr[ctr_idx] = 0;
+            const int64_t BH = (int64_t)a.batch * sq * a.heads;
+            for (int row = m0 + wave; row < min(m0 + BM, nrows); row += NW) {
+                const int pos = row / G, hh = hq + (row - pos * G);
+                const int64_t bh = ((int64_t)b * sq + pos) * a.heads + hh;
+                char* orow = obase + 2 * ((int64_t)pos * a.o_row_stride + (int64_t)(row - pos * G) * a.o_head_stride);
+                float* lse_out = a.lse ? a.lse + ((int64_t)b * a.heads + hh) * sq + pos : nullptr;
+                combine_row<T>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, lse_out, lane);
+            }
             return;
         }
         if (a.lse && h == 0 && qrow < nrows) a.lse[((int64_t)b * a.heads + hq + grp) * sq + qpos] = lse_row;
@@ -687,15 +712,75 @@ static int launch_mq_d(PrefillArgs& a, hipStream_t stream) {
 #undef MFA_MQ_CASE
 }
 
+// The in-kernel split merge orders partial stores and the arrival counter through ONE L2: it needs every key split of a
+// (batch, KV head) on the same XCD, which the launch arranges by workgroup id (id & 7 = XCD, the dispatcher's round robin).
+// That holds on every MI355X partition mode seen, but correctness must not hang on it: checked once per device with the
+// hardware's XCC_ID register; where it fails the merge stays a separate launch.
+__global__ void xcd_probe_kernel(int* mismatches) {
+    const int xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; // HW_REG_XCC_ID
+    if (threadIdx.x == 0 && xcc != (int)(blockIdx.x & 7)) atomicAdd(mismatches, 1);
+}
+static bool xcd_mapping_holds(int dev) {
+    static std::mutex mu;
+    static std::map<int, bool> known;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = known.find(dev);
+    if (it != known.end()) return it->second;
+    int* d = nullptr;
+    int h = -1;
+    bool ok = false;
+    if (hipMalloc(&d, sizeof(int)) == hipSuccess) {
+        if (hipMemset(d, 0, sizeof(int)) == hipSuccess) {
+            hipLaunchKernelGGL(xcd_probe_kernel, dim3(4096), dim3(64), 0, 0, d);
+            ok = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && h == 0;
+        }
+        (void)hipFree(d);
+    }
+    known[dev] = ok;
+    return ok;
+}
+
+// Arrival counters for the in-kernel split merge: one zeroed buffer per (device, stream) -- launches on a stream are
+// ordered, and the winning workgroup of every row block resets its counter, so the buffer is all zero between launches.
+// Returns null (the caller then launches decode_combine_kernel as before) when a buffer would have to be allocated while
+// the stream is being captured into a graph, or when MFA_FUSED_COMBINE=0.
+static int32_t* split_counters(hipStream_t stream, size_t n) {
+    static const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
+    if (!env) return nullptr;
+    struct Buf { int32_t* p; size_t n; };
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    Buf& b = bufs[{dev, stream}];
+    if (b.n >= n) return b.p;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    if (!xcd_mapping_holds(dev)) return nullptr;
+    const size_t want = std::max<size_t>(n, 1 << 16);
+    int32_t* np = nullptr;
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMalloc(&np, want * sizeof(int32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(np, 0, want * sizeof(int32_t)) != hipSuccess) { (void)hipFree(np); return nullptr; }
+    if (b.p) (void)hipFree(b.p); // (the stream was drained above: no launch still counts in the old buffer)
+    b = Buf{np, want};
+    return np;
+}
+
 int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream) {
     PrefillArgs a = make_args(p);
     a.cu_q = a.cu_k = nullptr;
     a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
     a.o_acc = p.oaccum_ptr;
     a.lse_acc = p.softmax_lseaccum_ptr;
+    a.split_ctr = nullptr;
+    if (a.num_splits > 1) {
+        const int64_t row_blocks = ((int64_t)a.seqlen_q * a.group + 127) / 128;
+        a.split_ctr = split_counters(stream, (size_t)((int64_t)a.batch * a.kv_heads * row_blocks));
+    }
     const int rc = p.is_bf16 ? launch_mq_d<BFloat>(a, stream) : launch_mq_d<Half>(a, stream);
     if (rc) return rc;
-    return a.num_splits > 1 ? launch_decode_combine(p, stream) : 0;
+    return a.num_splits > 1 && !a.split_ctr ? launch_decode_combine(p, stream) : 0;
 }
 
 } // namespace mfa

@@ -44,6 +44,8 @@ struct PrefillArgs {
     int32_t num_splits;       // key splits; > 1: normalised partial O and LSE go to o_acc / lse_acc
     float* o_acc;             // (splits, B, Sq, H, D) fp32
     float* lse_acc;           // (splits, B, Sq, H) fp32
+    int32_t* split_ctr;       // one arrival counter per (batch, KV head, row block), zero between launches: the last split
+                              // to arrive merges the partials itself (no combine launch); null: the caller launches it
 };
 
 // 64-rows-per-wave kernel (mfa_prefill64.hip).  Returns -2 when the shape / mode is not one it serves (the caller
