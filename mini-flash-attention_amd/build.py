@@ -57,12 +57,15 @@ def torch_lib_dir():
 
 
 def build_hip_lib(force=False):
-    os.makedirs(BUILD, exist_ok=True)
+    import hashlib
+    # objects are cached per flag set: a developer build (MFA_EXTRA_HIPCC_FLAGS) never leaks into the product library
+    objdir = os.path.join(BUILD, hashlib.sha1(" ".join(HIP_FLAGS).encode()).hexdigest()[:10])
+    os.makedirs(objdir, exist_ok=True)
     srcs = ["mfa_prefill.hip", "mfa_prefill64.hip", "mfa_decode.hip", "mfa_kvcache.hip", "mfa_capi.cpp"]
     objs, jobs = [], []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(BUILD, s.rsplit(".", 1)[0] + ".o")
+        obj = os.path.join(objdir, s.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + _headers()):
             cmd = [HIPCC] + HIP_FLAGS + (["-x", "hip"] if s.endswith(".cpp") else []) + ["-c", src, "-o", obj]
@@ -70,7 +73,9 @@ def build_hip_lib(force=False):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(_run, jobs))
     out = os.path.join(PKG, "libmfa_hip.so")
-    if force or jobs or _stale(out, objs):
+    tag = os.path.join(BUILD, "linked_from")  # (which flag set the library in the package was linked from)
+    last = open(tag).read() if os.path.exists(tag) else ""
+    if force or jobs or _stale(out, objs) or last != objdir:
         # Link against the HIP runtime by SONAME (libamdhip64.so.7).  Inside a torch process the loader
         # reuses the runtime torch already mapped (same SONAME), so streams and pointers are shared;
         # standalone it resolves through the rpath to ROCm's copy.
@@ -78,6 +83,8 @@ def build_hip_lib(force=False):
         cmd = [HIPCC, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + objs
         cmd += ["-Wl,-soname,libmfa_hip.so"] + [f"-Wl,-rpath,{p}" for p in rpaths]
         _run(cmd)
+        with open(tag, "w") as f:
+            f.write(objdir)
     return out
 
 

@@ -1,7 +1,8 @@
-// Developer-only scaffolding of prefill_fwd_kernel (mfa_prefill.hip): timing ablations and per-workgroup phase stamps.
+// Developer-only scaffolding of the prefill kernels: timing ablations and per-workgroup phase stamps.
 // A PRODUCT build sees none of it: every macro below is empty / false unless the library is built with
-//     MFA_EXTRA_HIPCC_FLAGS="-DMFA_DEV_ABL_MASK=<bits> [-DMFA_DEV_TIMELINE]" python mini-flash-attention_amd/build.py
-// (tools/ab_variants.sh, tools/wg_timeline.py).  Results of an ablated build are wrong by construction.
+//     MFA_EXTRA_HIPCC_FLAGS="-DMFA_DEV_ABL_MASK=<bits> [-DMFA_DEV_TIMELINE] [-DMFA_DEV_P64]" python mini-flash-attention_amd/build.py
+// (tools/abl.sh, tools/wg_timeline.py for prefill_fwd_kernel; tools/p64_timeline.py for prefill64_kernel, after
+// `python tools/gen_p64_stream.py --dev`).  Results of an ablated build are wrong by construction.
 //   bit 1    no next-tile DMA            bit 2    no end-of-tile barrier     bit 4   exp2 replaced by a move
 //   bit 8    no P.V MFMAs                bit 64   no end-of-tile vmcnt(0)    bit 256 no tiles (prologue + epilogue only)
 //   bit 512  rescale threshold 0         bit 2048 non-temporal DMA everywhere
@@ -35,4 +36,44 @@
 #define MFA_DEV_STAMP(i)
 #define MFA_DEV_TIMELINE_ON false
 #define MFA_DEV_STAMP_FLUSH(lse, tid, nt)
+#endif
+
+// ---- prefill64_kernel (mfa_prefill64.hip): stamps of the workgroup's first two work items by its last wave (16 x u64 per
+// workgroup at Sched::dev_ptr, MFA_P64_DEBUG bit 1) and timing-only variants of the loop block (MFA_P64_DEBUG >> 2)
+#ifdef MFA_DEV_P64
+#define MFA_DEV_P64_ENTRY const unsigned long long mfa_dev_t_entry = __builtin_amdgcn_s_memtime()
+#define MFA_DEV_P64_STAMPS(sc, wave, lane, NW)                                                                         \
+    unsigned long long* mfa_dev_stamps =                                                                               \
+        ((sc).dev_variant & 2) && (sc).dev_ptr && (wave) == (NW) - 1 && (lane) == 0 ? (sc).dev_ptr + (size_t)blockIdx.x * 16 : nullptr; \
+    int mfa_dev_items = 0
+#define MFA_DEV_P64_FIRST do { if (mfa_dev_stamps) mfa_dev_stamps[0] = mfa_dev_t_entry; } while (0)
+#define MFA_DEV_P64_STAMP(i) do { if (mfa_dev_stamps) mfa_dev_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MFA_DEV_P64_ITEM_DONE(nt, nt_w)                                                                                \
+    do {                                                                                                               \
+        if (mfa_dev_stamps) mfa_dev_stamps[7] = ((unsigned long long)(nt) << 32) | (unsigned)(nt_w);                   \
+        if (++mfa_dev_items == 2) mfa_dev_stamps = nullptr; /* the second item: the steady-state item boundary */       \
+        else if (mfa_dev_stamps) mfa_dev_stamps[0] = __builtin_amdgcn_s_memtime();                                     \
+    } while (0)
+#define MFA_DEV_P64_VARIANT(sc) (__builtin_expect(((sc).dev_variant >> 2) != 0, 0))
+#define MFA_DEV_P64_RUN_VARIANT(sc)                                                                                    \
+    do {                                                                                                               \
+        switch ((sc).dev_variant >> 2) {                                                                               \
+        case 1: P64_RUN(P64_STEADY_ABL1); break;                                                                       \
+        case 2: P64_RUN(P64_STEADY_ABL2); break;                                                                       \
+        case 3: P64_RUN(P64_STEADY_ABL3); break;                                                                       \
+        case 4: P64_RUN(P64_STEADY_ABL4); break;                                                                       \
+        case 5: P64_RUN(P64_STEADY_ABL5); break;                                                                       \
+        case 6: P64_RUN(P64_STEADY_ABL6); break;                                                                       \
+        case 7: P64_RUN(P64_STEADY_ABL7); break;                                                                       \
+        default: P64_RUN(P64_STEADY_ABL8); break;                                                                      \
+        }                                                                                                              \
+    } while (0)
+#else
+#define MFA_DEV_P64_ENTRY
+#define MFA_DEV_P64_STAMPS(sc, wave, lane, NW)
+#define MFA_DEV_P64_FIRST
+#define MFA_DEV_P64_STAMP(i)
+#define MFA_DEV_P64_ITEM_DONE(nt, nt_w)
+#define MFA_DEV_P64_VARIANT(sc) false
+#define MFA_DEV_P64_RUN_VARIANT(sc)
 #endif

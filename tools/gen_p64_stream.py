@@ -3,6 +3,7 @@
 (mfa_prefill64.hip) as inline-asm blocks, one text per element type, with every vector register named physically.
 
     python tools/gen_p64_stream.py            # rewrites the .inc (committed; build.py does not run this)
+    python tools/gen_p64_stream.py --dev      # + mfa_prefill64_stream_dev.inc: timing-only loop variants for -DMFA_DEV_P64 builds
 
 The kernel's whole tile loop runs out of a RESERVED part of the register file that hipcc never sees as variables:
 P64_INIT* takes the initial values as operands pinned to their home registers, every later block names the homes
@@ -74,6 +75,7 @@ Blocks (P = parity of a tile's S buffer, C = chain); scalar operands are named i
 The phases outside the loop read their own first fragments (no hand-over), so any sequence of them is valid.
 """
 import os
+import sys
 
 PF = 3          # fragments read ahead of their MFMAs (rings hold PF + 1)
 TILE = 16384
@@ -817,12 +819,6 @@ def main():
         emit_block(fh, "P64_FIRST0", lambda st: st.first_block(0), [], [C_OP])
         emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [], [KS, C_OP])
         emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
-        # timing-only variants of the steady loop (results are wrong): MFA_P64_DEBUG >> 2 = 1 + index
-        for n, tags in enumerate(ABLATIONS):
-            def ablated(st, tags=tags):
-                st.ablate = set(tags)
-                return st.steady()
-            emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins)
         for pn in range(2):
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
@@ -847,6 +843,17 @@ def main():
         fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
                  " : : \"memory\"\n")
     print("wrote", os.path.relpath(path, root))
+    if "--dev" in sys.argv:
+        # timing-only variants of the steady loop (results are wrong): developer builds (-DMFA_DEV_P64), MFA_P64_DEBUG >> 2 = 1 + index
+        dev = os.path.join(root, "mini-flash-attention_amd", "csrc", "mfa_prefill64_stream_dev.inc")
+        with open(dev, "w") as fh:
+            fh.write("// GENERATED by tools/gen_p64_stream.py --dev -- developer builds only (csrc/mfa_dev.h), not committed.\n\n")
+            for n, tags in enumerate(ABLATIONS):
+                def ablated(st, tags=tags):
+                    st.ablate = set(tags)
+                    return st.steady()
+                emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins)
+        print("wrote", os.path.relpath(dev, root))
 
 
 if __name__ == "__main__":

@@ -1,5 +1,9 @@
-"""Where a workgroup of prefill64_kernel spends its time: shader-clock stamps of wave 0 of every workgroup
-(developer aid; MFA_P64_DEBUG=2).   python tools/p64_timeline.py [S] [causal 0/1]"""
+"""Where a workgroup of prefill64_kernel spends its time: shader-clock stamps of the last wave of every workgroup, second
+work item (developer aid; needs a DEVELOPER build -- the stamps and the timing-only loop variants are compiled out of the
+product, csrc/mfa_dev.h):
+    python tools/gen_p64_stream.py --dev && MFA_EXTRA_HIPCC_FLAGS=-DMFA_DEV_P64 python mini-flash-attention_amd/build.py
+    python tools/p64_timeline.py [S] [causal 0/1] [4 * variant]
+    python mini-flash-attention_amd/build.py        # back to the product build"""
 import os, sys
 import torch
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
