@@ -245,8 +245,8 @@ def main():
     # power-state ramp of the first ~30 ms after an idle period -- which `sweep[*].cold` reports, shape by shape.
     sweeps = {}
     if not args.no_sweep:
-        sweeps["sweep"] = prefill_sweep(mfa, dev)
         sweeps["decode_sweep"] = decode_sweep(mfa, dev)
+        sweeps["sweep"] = prefill_sweep(mfa, dev)  # (last: the headline region follows the MFMA-heavy shapes directly)
         sweeps["regimes"] = ("cold = mean of the first 25 launches after a 0.25 s idle gap; steady = mean of 4-40 launches "
                              "after >= 0.3-0.5 s of back-to-back launches; HIP events on the launch stream; the headline, decode "
                              "and kvcache_packed regions run after the sweeps (settled clocks)")
