@@ -663,9 +663,11 @@ static PrefillArgs make_args(const mfa_forward_params& p) {
 
 int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     PrefillArgs a = make_args(p);
-    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip); MFA_PREFILL64=0 forces the general one
+    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip), except for keys that fit three tiles, where its
+    // longer way in and out of a work item costs more than its loop gains (B2 S128 H16: 9.9 vs 7.3 us; equal at S=256).
+    // MFA_PREFILL64=0 forces the general kernel, =2 the 64-row one for everything it serves (tests, tools).
     static const int env_p64 = [] { const char* e = getenv("MFA_PREFILL64"); return e ? atoi(e) : 1; }();
-    if (env_p64) {
+    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k > 192)) {
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
         if (rc != -2) return rc;
     }

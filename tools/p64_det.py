@@ -1,5 +1,6 @@
 import os, sys
 import torch
+os.environ.setdefault("MFA_PREFILL64", "2")  # every shape the 64-row kernel serves goes to it
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
 import torch.nn.functional as F
