@@ -277,8 +277,8 @@ int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip
     if (route == kKvDecode) {
         const int rc = mfa::launch_decode(*p, stream);
         if (rc == -4)
-            return fail(MFA_ERR_UNSUPPORTED, "decode launches (splits, kv_heads x head chunks, batch) workgroups: batch (%d) and "
-                        "kv_heads x ceil(group / 8) must each be <= 65535", p->batch);
+            return fail(MFA_ERR_UNSUPPORTED, "decode launches batch x kv_heads x head chunks x splits workgroups: the product must stay "
+                        "below 2^30 (batch %d)", p->batch);
         if (rc) return fail(MFA_ERR_LAUNCH, "decode launch failed: %s", hipGetErrorString(hipGetLastError()));
         return MFA_OK;
     }

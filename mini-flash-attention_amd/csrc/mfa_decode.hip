@@ -31,6 +31,8 @@ struct DecodeArgs {
     float* lse;      // (B,H) or null
     float* lse_acc;  // (S,B,H)
     float* o_acc;    // (S,B,H,D)
+    int32_t* split_ctr; // one arrival counter per (batch, KV head, head chunk), zero between launches: the last split to
+                        // arrive merges the partials itself; null: decode_combine_kernel is launched behind
     const int32_t* seqlens_k;
     const int32_t* block_table;
     int64_t q_batch_stride, q_head_stride;
@@ -82,10 +84,23 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     const int lg = lane / LPR;
     const bool col_ok = c * 8 < a.head_dim;
 
-    const int split = blockIdx.x;
-    const int hk = blockIdx.y / a.nchunks;
-    const int chunk = blockIdx.y % a.nchunks;
-    const int b = blockIdx.z;
+    // workgroup -> (row = (batch, KV head, head chunk), split): 1-D and XCD-aware -- workgroups bid, bid + 8, ... share an
+    // XCD (round-robin dispatch), XCD x owns a contiguous range of rows and all splits of a row, so that the partials
+    // of a row meet in one L2 (the in-kernel merge below relies on it; launch_decode_t checks the premise)
+    int split, row;
+    {
+        const int R = a.batch * a.kv_heads * a.nchunks;
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        const int r8 = R >> 3, rr = R & 7;
+        const int row_begin = x < rr ? x * (r8 + 1) : rr * (r8 + 1) + (x - rr) * r8;
+        const int ri = k / a.num_splits;
+        if (ri >= r8 + (x < rr ? 1 : 0)) return;
+        split = k - ri * a.num_splits;
+        row = row_begin + ri;
+    }
+    const int b = row / (a.kv_heads * a.nchunks);
+    const int hk = (row - b * a.kv_heads * a.nchunks) / a.nchunks;
+    const int chunk = row - (b * a.kv_heads + hk) * a.nchunks;
     const int g0 = chunk * GT; // first query head (within the group) of this workgroup
 
     int len = a.seqlens_k ? a.seqlens_k[b] + a.seqlens_k_offset : a.seqlen_k;
@@ -310,6 +325,25 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
             if (d == 0 && a.lse) a.lse[(int64_t)b * a.heads + hq] = lse;
         }
     }
+    if (a.num_splits > 1 && a.split_ctr) {
+        // the last split of this row to arrive merges the partials (as the packed-row kernels do, mfa_prefill.hip): stores
+        // drained into the XCD's L2, one ticket per workgroup, acquire and counter reset in the winner, one wave per head
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* const flag = (int*)smem;
+        if (threadIdx.x == 0) *flag = atomicAdd(a.split_ctr + row, 1);
+        __syncthreads();
+        if (*flag != a.num_splits - 1) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (threadIdx.x == 0) a.split_ctr[row] = 0;
+        const int64_t BH = (int64_t)a.batch * a.heads;
+        for (int g = wave; g < GT && g0 + g < a.group; g += kDecodeWaves) {
+            const int hq = hk * a.group + g0 + g;
+            const int64_t bh = (int64_t)b * a.heads + hq;
+            char* orow = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)hq * a.o_head_stride);
+            combine_row<T>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, a.lse ? a.lse + bh : nullptr, lane);
+        }
+    }
 }
 
 // The split merge as its own launch: one WAVE per (batch, query position, head) row, four rows per workgroup
@@ -333,7 +367,8 @@ __global__ __launch_bounds__(64 * kCombineRows) void decode_combine_kernel(const
 
 template <typename T, int LPR, int GT>
 static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
-    dim3 grid(a.num_splits, a.kv_heads * a.nchunks, a.batch);
+    const int64_t R = (int64_t)a.batch * a.kv_heads * a.nchunks;
+    dim3 grid((unsigned)(8 * ((R >> 3) + ((R & 7) ? 1 : 0)) * a.num_splits));
     const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
     if (!a.block_table)
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kDense>), grid, dim3(kDecodeThreads), smem, stream, a);
@@ -343,7 +378,7 @@ static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedPow2>), grid, dim3(kDecodeThreads), smem, stream, a);
     else
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kPagedDiv>), grid, dim3(kDecodeThreads), smem, stream, a);
-    if (a.num_splits > 1) {
+    if (a.num_splits > 1 && !a.split_ctr) {
         const int64_t BH = (int64_t)a.batch * a.heads;
         hipLaunchKernelGGL((decode_combine_kernel<T>), dim3((unsigned)((BH + kCombineRows - 1) / kCombineRows)), dim3(64 * kCombineRows), 0, stream, a);
     }
@@ -404,7 +439,8 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream) {
         if (gt == 7) gt = 8;
     }
     a.nchunks = (G + gt - 1) / gt;
-    if (a.batch > 65535 || (int64_t)a.kv_heads * a.nchunks > 65535) return -4; // grid.z / grid.y limits
+    if ((int64_t)a.batch * a.kv_heads * a.nchunks * a.num_splits >= (1LL << 30)) return -4; // (1-D grid)
+    a.split_ctr = a.num_splits > 1 ? split_counters(stream, (size_t)a.batch * a.kv_heads * a.nchunks) : nullptr;
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
 }
 

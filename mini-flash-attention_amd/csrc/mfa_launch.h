@@ -18,6 +18,10 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream);
 int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream);
 int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream);
 
+// Arrival counters for the in-kernel merge of key splits (mfa_prefill.hip): n zeroed int32 for this (device, stream), or
+// null when the merge has to stay a separate launch (see there).  The kernels leave them zeroed.
+int32_t* split_counters(hipStream_t stream, size_t n);
+
 // KV-cache append (no reference counterpart: see include/mfa.h).
 int launch_kvcache_append(const mfa_kvcache_append_params& p, hipStream_t stream);
 

@@ -746,7 +746,7 @@ static bool xcd_mapping_holds(int dev) {
 // ordered, and the winning workgroup of every row block resets its counter, so the buffer is all zero between launches.
 // Returns null (the caller then launches decode_combine_kernel as before) when a buffer would have to be allocated while
 // the stream is being captured into a graph, or when MFA_FUSED_COMBINE=0.
-static int32_t* split_counters(hipStream_t stream, size_t n) {
+int32_t* split_counters(hipStream_t stream, size_t n) {
     static const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
     if (!env) return nullptr;
     struct Buf { int32_t* p; size_t n; };
