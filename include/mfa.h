@@ -24,7 +24,9 @@
  * index is masked, csrc/mfa/prefill.cuh:416-419); inputs are fp16 or bf16, accumulation is fp32.
  *
  * All launches are asynchronous on `stream`; inputs are borrowed until the enqueued kernels
- * finish.  No entry point allocates, frees or synchronises (hipGraph-capturable).
+ * finish.  No LAUNCH entry point (mfa_run_*, mfa_kvcache_append) allocates, frees or synchronises: they are
+ * hipGraph-capturable and every buffer they touch is the caller's.  The one entry that does touch the device on
+ * its own is the optional mfa_init() below (a probe launch + a blocking copy; never called implicitly).
  * Return value: 0 on success, a negative MFA_ERR_* code otherwise; mfa_last_error() gives the
  * message for the calling thread.
  */
@@ -38,7 +40,7 @@
 extern "C" {
 #endif
 
-#define MFA_ABI_VERSION 3
+#define MFA_ABI_VERSION 4
 
 enum {
     MFA_OK = 0,
@@ -113,6 +115,17 @@ typedef struct mfa_forward_params {
     int64_t total_q;            /* varlen: rows of q (layout of the LSE output)                */
     int32_t seqlens_k_offset;   /* added to every seqlens_k[b] (keys just appended by mfa_kvcache_append)     */
     int32_t reserved;
+    /* kv-cache entry with num_splits > 1, optional: arrival counters for the IN-KERNEL merge of the key splits (the last
+     * split of a row to arrive merges the partials in its own epilogue instead of a second launch).  A caller-owned int32
+     * buffer of at least mfa_kvcache_counter_count(p) entries, all ZERO before the first launch that uses it; the kernels
+     * leave it zero, so it can be reused by every later launch ON THE SAME STREAM (launches that may run concurrently
+     * need buffers of their own) and must outlive any hipGraph that captured a launch with it.  NULL, too short, or
+     * mfa_init() not called / failed for the device: the merge is decode_combine_kernel's own launch (the reference's
+     * structure, flash.cu:60-70).  Premise of the in-kernel merge, verified by mfa_init(): workgroups whose ids are equal
+     * mod 8 run on one XCD (the dispatcher's round robin), so the partials of a row meet in one L2; on a stream created
+     * with a CU mask pass NULL. */
+    int32_t* split_counters;
+    int64_t split_counters_len; /* entries */
 } mfa_forward_params;
 
 /* KV-cache append: copy new K/V rows (B, Sn, Hkv, D) into the cache at positions seqlens_k[b] .. +Sn-1 (dense
@@ -157,6 +170,31 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
  * p->num_splits must already be resolved (>= 1, from mfa_kvcache_plan); workspaces must be present when it is > 1. */
 int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream);
 
+/* Optional, once per device (-1 = current), NOT capturable: checks on the hardware that workgroup ids equal mod 8 share
+ * an XCD (HW_REG_XCC_ID), the premise of the in-kernel split merge.  Allocates 4 bytes, launches a probe on the null
+ * stream, copies the answer back (blocking) and frees.  Returns 1 when the premise holds (the merge may be used on
+ * this device from now on), 0 when it does not (split_counters is ignored), < 0 on a HIP error.  Thread-safe; repeated
+ * calls return the cached answer. */
+int mfa_init(int device);
+
+/* int32 entries the kv-cache entry would use from p->split_counters for this problem (p->num_splits resolved by
+ * mfa_kvcache_plan): 0 when the launch is unsplit or when the library keeps the merge as its own launch for this size
+ * (large launches, where the merge launch is cheaper than the winners' cache invalidations).  Never more than
+ * MFA_SPLIT_COUNTERS_MAX, so a caller may allocate that many once. */
+size_t mfa_kvcache_counter_count(const mfa_forward_params* p);
+#define MFA_SPLIT_COUNTERS_MAX 65536
+
+/* Which kernels the calling thread's last successful mfa_run_flash_attention_with_kv_cache() launched: a test / tracing
+ * aid (the reference has no counterpart).  MFA_ROUTE_* bits. */
+enum {
+    MFA_ROUTE_DECODE = 1,       /* vector flash-decoding kernel (mfa_decode.hip)                         */
+    MFA_ROUTE_PACKED = 2,       /* packed-row MFMA kernel (MQ instances, mfa_prefill.hip)                */
+    MFA_ROUTE_PREFILL = 4,      /* per-head prefill kernel over the cache                                */
+    MFA_ROUTE_COMBINE_LAUNCH = 8, /* split merge as decode_combine_kernel's own launch                  */
+    MFA_ROUTE_FUSED_MERGE = 16  /* split merge inside the split kernel (split_counters used)             */
+};
+int mfa_debug_last_route(void);
+
 /* What the kv-cache entry wants for this problem (shape fields, num_cus and num_splits of *p are read; num_splits
  * < 1 = choose): the key-split count to put into p->num_splits and the bytes of the two fp32 workspaces
  * (oaccum: (S,B,Sq,H,D), lseaccum: (S,B,Sq,H); both 0 when S == 1).  For seqlen_q == 1 and a GQA group <= 4 this
@@ -175,6 +213,10 @@ int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_
  * for (S,B,H).  Both are 0 when num_splits <= 1. */
 void mfa_decode_workspace_bytes(int num_splits, int batch, int heads, int head_dim,
                                 size_t* oaccum_bytes, size_t* lse_bytes);
+
+/* 1 while `hip_stream` is being captured into a hipGraph, 0 when not, < 0 on a HIP error (a host that owns
+ * split_counters buffers must not create one during a capture). */
+int mfa_stream_is_capturing(void* hip_stream);
 
 /* Number of compute units of HIP device `device` (-1 = current); <0 on error. */
 int mfa_device_cu_count(int device);

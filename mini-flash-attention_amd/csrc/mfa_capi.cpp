@@ -18,6 +18,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local int g_last_route = 0; // MFA_ROUTE_* bits of this thread's last successful kv-cache call
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -102,12 +103,27 @@ int mfa_kvcache_append(const mfa_kvcache_append_params* p, void* hip_stream) {
     return MFA_OK;
 }
 
+int mfa_debug_last_route(void) { return g_last_route; }
+
+int mfa_init(int device) {
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return fail(MFA_ERR_LAUNCH, "hipGetDevice failed");
+    const int rc = mfa::xcd_premise_probe(device);
+    if (rc < 0) return fail(MFA_ERR_LAUNCH, "mfa_init: XCD probe failed on device %d: %s", device, hipGetErrorString(hipGetLastError()));
+    return rc;
+}
+
 void mfa_forward_params_set_scale(mfa_forward_params* p) {
     if (!p || p->head_dim <= 0) return;
     // reference: csrc/mfa/api.cpp:84, 99-100
     p->kv_group_size = p->kv_heads > 0 ? p->heads / p->kv_heads : 0;
     p->softmax_scale = 1.0f / std::sqrt(static_cast<float>(p->head_dim));
     p->softmax_scale_log2 = static_cast<float>(p->softmax_scale * 1.4426950408889634074);
+}
+
+int mfa_stream_is_capturing(void* hip_stream) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(static_cast<hipStream_t>(hip_stream), &cs) != hipSuccess) return fail(MFA_ERR_LAUNCH, "hipStreamIsCapturing failed");
+    return cs != hipStreamCaptureStatusNone ? 1 : 0;
 }
 
 int mfa_device_cu_count(int device) {
@@ -259,6 +275,26 @@ int mfa_kvcache_plan(const mfa_forward_params* p, int* num_splits, size_t* oaccu
     return MFA_OK;
 }
 
+// counters of the in-kernel merge for this problem (the launchers use the same arithmetic): one per (batch, KV head, head
+// chunk) for the vector kernel, one per (batch, KV head, block of 128 packed rows) for the packed kernel
+static int64_t decode_head_chunks(int g) { // (mfa_decode.hip launch_decode: group tiles of 1-4, 6, 8 heads)
+    const int gt = g <= 4 ? g : (g <= 6 ? 6 : 8);
+    return (g + gt - 1) / gt;
+}
+size_t mfa_kvcache_counter_count(const mfa_forward_params* p) {
+    if (!p || p->num_splits <= 1 || p->kv_heads <= 0 || p->heads % p->kv_heads != 0 || p->seqlen_q < 1) return 0;
+    const int g = p->heads / p->kv_heads;
+    int64_t n = 0;
+    mfa_forward_params one = *p;
+    switch (kvcache_route(p)) {
+    case kKvDecode: n = (int64_t)p->batch * p->kv_heads * decode_head_chunks(g); one.seqlen_q = 1; break;
+    case kKvPacked: n = (int64_t)p->batch * p->kv_heads * (((int64_t)p->seqlen_q * g + 127) / 128); break;
+    default: return 0;
+    }
+    if (n > MFA_SPLIT_COUNTERS_MAX || !mfa::fused_merge_pays(n * p->num_splits, mfa::partial_bytes(one))) return 0;
+    return (size_t)n;
+}
+
 int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip_stream) {
     if (int rc = check_common(p)) return rc;
     if (p->seqlen_q < 1) return fail(MFA_ERR_INVALID_ARGUMENT, "seqlen_q must be >= 1, got %d", p->seqlen_q);
@@ -275,11 +311,13 @@ int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip
     const hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     const int route = kvcache_route(p);
     if (route == kKvDecode) {
-        const int rc = mfa::launch_decode(*p, stream);
+        bool fused = false;
+        const int rc = mfa::launch_decode(*p, stream, &fused);
         if (rc == -4)
             return fail(MFA_ERR_UNSUPPORTED, "decode launches batch x kv_heads x head chunks x splits workgroups: the product must stay "
                         "below 2^30 (batch %d)", p->batch);
         if (rc) return fail(MFA_ERR_LAUNCH, "decode launch failed: %s", hipGetErrorString(hipGetLastError()));
+        g_last_route = MFA_ROUTE_DECODE | (p->num_splits > 1 ? (fused ? MFA_ROUTE_FUSED_MERGE : MFA_ROUTE_COMBINE_LAUNCH) : 0);
         return MFA_OK;
     }
     // the queries are the LAST seqlen_q positions of the sequence: causal / windows align to the last key
@@ -292,10 +330,13 @@ int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip
         if (p->num_splits > 1) return fail(MFA_ERR_INVALID_ARGUMENT, "this shape runs unsplit: ask mfa_kvcache_plan for num_splits");
         const int rc = mfa::launch_prefill(q, stream);
         if (rc) return fail(MFA_ERR_LAUNCH, "kv-cache prefill launch failed: %s", hipGetErrorString(hipGetLastError()));
+        g_last_route = MFA_ROUTE_PREFILL;
         return MFA_OK;
     }
-    const int rc = mfa::launch_kvcache_packed(q, stream);
+    bool fused = false;
+    const int rc = mfa::launch_kvcache_packed(q, stream, &fused);
     if (rc) return fail(MFA_ERR_LAUNCH, "packed kv-cache launch failed: %s", hipGetErrorString(hipGetLastError()));
+    g_last_route = MFA_ROUTE_PACKED | (p->num_splits > 1 ? (fused ? MFA_ROUTE_FUSED_MERGE : MFA_ROUTE_COMBINE_LAUNCH) : 0);
     return MFA_OK;
 }
 

@@ -10,17 +10,28 @@ namespace mfa {
 // Prefill / varlen / paged prefill (replaces run_mha_prefill, reference csrc/mfa/flash.cu:11-34).
 int launch_prefill(const mfa_forward_params& p, hipStream_t stream);
 
-// Decode + optional combine (replaces run_mha_decode, reference csrc/mfa/flash.cu:36-71).
-int launch_decode(const mfa_forward_params& p, hipStream_t stream);
+// Decode + optional combine (replaces run_mha_decode, reference csrc/mfa/flash.cu:36-71).  *merged_in_kernel (may be
+// null): whether the split merge ran inside the split kernel (false: unsplit, or decode_combine_kernel launched behind).
+int launch_decode(const mfa_forward_params& p, hipStream_t stream, bool* merged_in_kernel);
 
 // Packed-row kv-cache attention, seqlen_q >= 1 (MQ instances of the prefill kernel, mfa_prefill.hip) with p.num_splits
 // key splits and, when > 1, the combine below.  Returns -2 when no instance exists for the head dim.
-int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream);
+int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream, bool* merged_in_kernel);
 int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream);
 
-// Arrival counters for the in-kernel merge of key splits (mfa_prefill.hip): n zeroed int32 for this (device, stream), or
-// null when the merge has to stay a separate launch (see there).  The kernels leave them zeroed.
-int32_t* split_counters(hipStream_t stream, size_t n);
+// In-kernel merge of key splits (mfa_prefill.hip).  xcd_premise_probe: mfa_init()'s check that workgroup ids equal mod 8
+// share an XCD (1 / 0 / <0 on a HIP error; cached per device; allocates and synchronises -- never on a launch path).
+// pick_split_counters: the caller's counters (mfa_forward_params::split_counters) when the merge of this launch should
+// and may run in the split kernel -- n counters needed, `workgroups` in the split launch, `partial_bytes` of fp32
+// partials -- else null (the launcher then runs decode_combine_kernel behind the split kernel).
+int xcd_premise_probe(int device);
+bool fused_merge_pays(int64_t workgroups, int64_t pbytes);
+int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t workgroups, int64_t pbytes);
+constexpr int64_t kFusedMergeMaxWorkgroups = 512; // (two per CU: one round of the split kernel)
+constexpr int64_t kFusedMergeMaxPartialBytes = 8 << 20;
+inline int64_t partial_bytes(const mfa_forward_params& p) { // (S, B, Sq, H, D) + (S, B, Sq, H) fp32
+    return p.num_splits > 1 ? 4ll * p.num_splits * p.batch * p.seqlen_q * p.heads * (p.head_dim + 1) : 0;
+}
 
 // KV-cache append (no reference counterpart: see include/mfa.h).
 int launch_kvcache_append(const mfa_kvcache_append_params& p, hipStream_t stream);

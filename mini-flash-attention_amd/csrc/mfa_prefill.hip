@@ -19,9 +19,8 @@
 //   * workgroups are numbered so that the query blocks and query heads sharing one (batch, KV head)
 //     run on one XCD (shared L2), heaviest causal blocks first.
 #include <algorithm>
-#include <map>
+#include <atomic>
 #include <mutex>
-#include <utility>
 #include <cstdlib>
 #include <type_traits>
 
@@ -716,60 +715,82 @@ static int launch_mq_d(PrefillArgs& a, hipStream_t stream) {
 
 // The in-kernel split merge orders partial stores and the arrival counter through ONE L2: it needs every key split of a
 // (batch, KV head) on the same XCD, which the launch arranges by workgroup id (id & 7 = XCD, the dispatcher's round robin).
-// That holds on every MI355X partition mode seen, but correctness must not hang on it: checked once per device with the
-// hardware's XCC_ID register; where it fails the merge stays a separate launch.
+// That holds on every MI355X partition mode seen, but correctness must not hang on it: mfa_init() (include/mfa.h) checks it
+// per device with the hardware's XCC_ID register; until it has, and where it fails, the merge stays a separate launch.
+// No launch entry point runs the probe: it allocates and synchronises.
 __global__ void xcd_probe_kernel(int* mismatches) {
     const int xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf; // HW_REG_XCC_ID
-    if (threadIdx.x == 0 && xcc != (int)(blockIdx.x & 7)) atomicAdd(mismatches, 1);
+    __shared__ int first;
+    // (which XCD workgroup 0 lands on is not fixed: compare against the XCD of the workgroup's own residue class, recorded
+    //  by its first member to arrive)
+    if (threadIdx.x == 0) {
+        int* slot = mismatches + 1 + (blockIdx.x & 7);
+        const int seen = atomicCAS(slot, -1, xcc);
+        first = seen == -1 ? xcc : seen;
+        if (first != xcc) atomicAdd(mismatches, 1);
+    }
 }
-static bool xcd_mapping_holds(int dev) {
+namespace {
+constexpr int kMaxDevices = 64;
+std::atomic<int> g_xcd_state[kMaxDevices]; // 0 = not probed, 1 = premise holds, 2 = it does not
+}
+int xcd_premise_probe(int dev) {
+    if (dev < 0 || dev >= kMaxDevices) return 0;
+    const int st = g_xcd_state[dev].load();
+    if (st) return st == 1;
     static std::mutex mu;
-    static std::map<int, bool> known;
     std::lock_guard<std::mutex> lock(mu);
-    auto it = known.find(dev);
-    if (it != known.end()) return it->second;
+    if (g_xcd_state[dev].load()) return g_xcd_state[dev].load() == 1;
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess || hipSetDevice(dev) != hipSuccess) return -1;
     int* d = nullptr;
-    int h = -1;
-    bool ok = false;
-    if (hipMalloc(&d, sizeof(int)) == hipSuccess) {
-        if (hipMemset(d, 0, sizeof(int)) == hipSuccess) {
+    int h[9];
+    int rc = -1;
+    if (hipMalloc(&d, sizeof(h)) == hipSuccess) {
+        h[0] = 0;
+        for (int i = 1; i < 9; ++i) h[i] = -1;
+        if (hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) == hipSuccess) {
             hipLaunchKernelGGL(xcd_probe_kernel, dim3(4096), dim3(64), 0, 0, d);
-            ok = hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && h == 0;
+            if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                bool distinct = true; // eight residue classes on eight different XCDs, no workgroup off its class's XCD
+                for (int i = 1; i < 9; ++i)
+                    for (int j = i + 1; j < 9; ++j) distinct = distinct && h[i] != h[j];
+                rc = h[0] == 0 && distinct ? 1 : 0;
+            }
         }
         (void)hipFree(d);
     }
-    known[dev] = ok;
-    return ok;
+    (void)hipSetDevice(prev);
+    if (rc >= 0) g_xcd_state[dev].store(rc == 1 ? 1 : 2);
+    return rc;
 }
 
-// Arrival counters for the in-kernel split merge: one zeroed buffer per (device, stream) -- launches on a stream are
-// ordered, and the winning workgroup of every row block resets its counter, so the buffer is all zero between launches.
-// Returns null (the caller then launches decode_combine_kernel as before) when a buffer would have to be allocated while
-// the stream is being captured into a graph, or when MFA_FUSED_COMBINE=0.
-int32_t* split_counters(hipStream_t stream, size_t n) {
+// Whether the merge of `splits` key splits runs inside the split kernel for a launch of `workgroups` workgroups writing
+// `partial_bytes` of fp32 partials, and with which counters: the caller's (mfa_forward_params::split_counters, zeroed, at
+// least n entries), provided mfa_init() found the XCD premise to hold on this device.  Otherwise null: the caller of this
+// function launches decode_combine_kernel behind the split kernel.
+bool fused_merge_pays(int64_t workgroups, int64_t pbytes) {
+    // Measured (tools/ab_decode_map.py, one box, interleaved rounds; profiles/r03a_ab_decode_map_and_merge.txt): the
+    // in-kernel merge saves 1.0-1.3 us of 15-30 us on launches of at most one round of workgroups (256: B4 Skv8192, B8
+    // Skv4096, B16 Skv2048; 512 on the packed kernel: BASELINE config 5, 50.9 -> 49.2 us) and LOSES where later rounds
+    // of streaming workgroups queue behind the winners' invalidate and re-read: 768 workgroups +1.0 us (config 3 forced
+    // to 4 splits), 1 152 +6.6 us of 32 (README MHA B24 H24 Skv512), 1 536 +0.9 us (G=8, Skv8192).
+    return workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes;
+}
+int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t workgroups, int64_t pbytes) {
+#ifdef MFA_DEV_DECODE_AB // developer A/B builds: read per launch; =2: no size gate
+    const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
+#else
     static const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
-    if (!env) return nullptr;
-    struct Buf { int32_t* p; size_t n; };
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, Buf> bufs;
+#endif
+    if (!env || !p.split_counters || (size_t)(p.split_counters_len < 0 ? 0 : p.split_counters_len) < n) return nullptr;
+    if (env != 2 && !fused_merge_pays(workgroups, pbytes)) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    Buf& b = bufs[{dev, stream}];
-    if (b.n >= n) return b.p;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    if (!xcd_mapping_holds(dev)) return nullptr;
-    const size_t want = std::max<size_t>(n, 1 << 16);
-    int32_t* np = nullptr;
-    if (hipStreamSynchronize(stream) != hipSuccess || hipMalloc(&np, want * sizeof(int32_t)) != hipSuccess) return nullptr;
-    if (hipMemset(np, 0, want * sizeof(int32_t)) != hipSuccess) { (void)hipFree(np); return nullptr; }
-    if (b.p) (void)hipFree(b.p); // (the stream was drained above: no launch still counts in the old buffer)
-    b = Buf{np, want};
-    return np;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || g_xcd_state[dev].load() != 1) return nullptr;
+    return p.split_counters;
 }
 
-int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream) {
+int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream, bool* merged_in_kernel) {
     PrefillArgs a = make_args(p);
     a.cu_q = a.cu_k = nullptr;
     a.num_splits = p.num_splits < 1 ? 1 : p.num_splits;
@@ -778,10 +799,12 @@ int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream) {
     a.split_ctr = nullptr;
     if (a.num_splits > 1) {
         const int64_t row_blocks = ((int64_t)a.seqlen_q * a.group + 127) / 128;
-        a.split_ctr = split_counters(stream, (size_t)((int64_t)a.batch * a.kv_heads * row_blocks));
+        const int64_t n = (int64_t)a.batch * a.kv_heads * row_blocks;
+        a.split_ctr = pick_split_counters(p, (size_t)n, n * a.num_splits, partial_bytes(p));
     }
     const int rc = p.is_bf16 ? launch_mq_d<BFloat>(a, stream) : launch_mq_d<Half>(a, stream);
     if (rc) return rc;
+    if (merged_in_kernel) *merged_in_kernel = a.num_splits > 1 && a.split_ctr != nullptr;
     return a.num_splits > 1 && !a.split_ctr ? launch_decode_combine(p, stream) : 0;
 }
 

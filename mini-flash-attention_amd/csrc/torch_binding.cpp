@@ -9,8 +9,11 @@
 #include <torch/extension.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <optional>
 #include <tuple>
+#include <utility>
 
 #include "mfa.h"
 
@@ -93,6 +96,28 @@ void set_paged(mfa_forward_params& p, const at::Tensor& block_table, const at::T
 // kv-cache launch: asks the library for its key-split count and workspace sizes (reference:
 // forward_params_set_split_kv, api.cpp:305-340; the kernels write -inf LSE for empty splits themselves, so no fill
 // kernel is launched), allocates them from the caching allocator and runs.
+//
+// Arrival counters of the in-kernel split merge (mfa_forward_params::split_counters): the C ABI never allocates, so this
+// layer owns them -- one zeroed MFA_SPLIT_COUNTERS_MAX-entry int32 tensor per (device, stream), created at the first split
+// call on that stream together with the once-per-device mfa_init() probe, kept for the life of the process (never grown or
+// freed: a hipGraph that captured a launch keeps a valid pointer).  While the stream is being captured nothing is created:
+// a launch without counters merges through decode_combine_kernel, which captures like any other launch.
+static int32_t* split_counters_for(const at::Tensor& q, void* stream) {
+    static std::mutex mu;
+    static std::map<std::pair<int, void*>, at::Tensor> bufs;
+    static std::map<int, int> inited;
+    const int dev = q.device().index();
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = bufs.find({dev, stream});
+    if (it != bufs.end()) return it->second.data_ptr<int32_t>();
+    if (mfa_stream_is_capturing(stream) != 0) return nullptr;
+    if (!inited.count(dev)) inited[dev] = mfa_init(dev);
+    if (inited[dev] != 1) return nullptr;
+    at::Tensor t = at::zeros({MFA_SPLIT_COUNTERS_MAX}, q.options().dtype(at::kInt));
+    bufs.emplace(std::make_pair(dev, stream), t);
+    return t.data_ptr<int32_t>();
+}
+
 static void run_kvcache(mfa_forward_params& p, const at::Tensor& q, int requested_splits) {
     p.num_splits = requested_splits;
     int splits = 1;
@@ -100,14 +125,19 @@ static void run_kvcache(mfa_forward_params& p, const at::Tensor& q, int requeste
     check_rc(mfa_kvcache_plan(&p, &splits, &o_bytes, &lse_bytes));
     p.num_splits = splits;
     at::Tensor lse_accum, out_accum;
+    void* stream = current_stream(q);
     if (splits > 1) {
         auto opts = q.options().dtype(at::kFloat);
         lse_accum = at::empty({static_cast<int64_t>(lse_bytes / sizeof(float))}, opts);
         out_accum = at::empty({static_cast<int64_t>(o_bytes / sizeof(float))}, opts);
         p.softmax_lseaccum_ptr = lse_accum.data_ptr<float>();
         p.oaccum_ptr = out_accum.data_ptr<float>();
+        if (mfa_kvcache_counter_count(&p) > 0) {
+            p.split_counters = split_counters_for(q, stream);
+            p.split_counters_len = p.split_counters ? MFA_SPLIT_COUNTERS_MAX : 0;
+        }
     }
-    check_rc(mfa_run_flash_attention_with_kv_cache(&p, current_stream(q)));
+    check_rc(mfa_run_flash_attention_with_kv_cache(&p, stream));
 }
 
 // reference: mfa::flash_attention_forward, csrc/mfa/api.cpp:113-186

@@ -16,6 +16,8 @@ MFA_ERR_INVALID_ARGUMENT = -1
 MFA_ERR_UNSUPPORTED = -2
 MFA_ERR_LAUNCH = -3
 MFA_ERR_WORKSPACE = -4
+MFA_SPLIT_COUNTERS_MAX = 65536
+MFA_ROUTE_DECODE, MFA_ROUTE_PACKED, MFA_ROUTE_PREFILL, MFA_ROUTE_COMBINE_LAUNCH, MFA_ROUTE_FUSED_MERGE = 1, 2, 4, 8, 16
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
 
@@ -43,6 +45,7 @@ class ForwardParams(ctypes.Structure):
         ("max_blocks_per_seq", _i32), ("num_cus", _i32), ("mask_bottom_right", _i32),
         ("use_local_window", _i32), ("local_window_left", _i32), ("local_window_right", _i32),
         ("total_q", _i64), ("seqlens_k_offset", _i32), ("reserved", _i32),
+        ("split_counters", _vp), ("split_counters_len", _i64),
     ]
 
 
@@ -92,6 +95,13 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.mfa_decode_workspace_bytes.restype = None
     lib.mfa_kvcache_plan.argtypes = [P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     lib.mfa_kvcache_plan.restype = ctypes.c_int
+    lib.mfa_init.argtypes = [ctypes.c_int]
+    lib.mfa_init.restype = ctypes.c_int
+    lib.mfa_kvcache_counter_count.argtypes = [P]
+    lib.mfa_kvcache_counter_count.restype = ctypes.c_size_t
+    lib.mfa_debug_last_route.restype = ctypes.c_int
+    lib.mfa_stream_is_capturing.argtypes = [_vp]
+    lib.mfa_stream_is_capturing.restype = ctypes.c_int
     lib.mfa_device_cu_count.argtypes = [ctypes.c_int]
     lib.mfa_device_cu_count.restype = ctypes.c_int
     _lib = lib

@@ -9,8 +9,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "mini-flash-attention_amd"))
 import mini_flash_attention as mfa  # noqa: E402
 
+from mini_flash_attention import capi  # noqa: E402  (the same libmfa_hip.so the extension is linked to)
+
 dev = torch.device("cuda", 0)
 out = {}
+routes = []
 g = torch.Generator().manual_seed(7)
 # (B, Sq, Hq, Hk, Sk, D, page or 0, splits)
 cases = [(3, 1, 6, 2, 2500, 128, 0, 5), (2, 1, 8, 8, 4100, 64, 0, 7), (4, 1, 4, 1, 1500, 128, 0, 0), (1, 1, 24, 8, 9000, 128, 0, 0),
@@ -33,6 +36,7 @@ for n, (B, Sq, Hq, Hk, Sk, D, page, splits) in enumerate(cases):
         o = mfa.flash_attn_with_kvcache(q, kp, vp, block_table=perm.int().view(B, nb), **kw)
     else:
         o = mfa.flash_attn_with_kvcache(q, kc, vc, **kw)
+    routes.append(capi.load().mfa_debug_last_route())
     for rep in range(3):  # (the arrival counters must be back at zero: repeated launches agree bit for bit)
         o2 = mfa.flash_attn_with_kvcache(q, kp, vp, block_table=perm.int().view(B, nb), **kw) if page else mfa.flash_attn_with_kvcache(q, kc, vc, **kw)
         assert torch.equal(o, o2), f"case {n}: launch {rep + 2} differs from the first"
@@ -40,3 +44,4 @@ for n, (B, Sq, Hq, Hk, Sk, D, page, splits) in enumerate(cases):
 torch.cuda.synchronize()
 torch.save(out, sys.argv[1])
 print("saved", len(out))
+print("routes", " ".join(str(r) for r in routes))

@@ -17,6 +17,21 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_COUNTERS = {}
+
+
+def split_counters(capi, p):
+    """What a non-torch host does for the in-kernel split merge (include/mfa.h): mfa_init() once per device, one zeroed
+    int32 buffer per stream that lives as long as the process, handed over when the plan wants counters."""
+    lib = capi.load()
+    if lib.mfa_kvcache_counter_count(ctypes.byref(p)) == 0 or lib.mfa_init(-1) != 1:
+        return
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    if key not in _COUNTERS:
+        _COUNTERS[key] = torch.zeros(capi.MFA_SPLIT_COUNTERS_MAX, dtype=torch.int32, device="cuda")
+    p.split_counters, p.split_counters_len = _COUNTERS[key].data_ptr(), capi.MFA_SPLIT_COUNTERS_MAX
+
+
 def _check(capi, rc):
     assert rc == 0, f"C ABI returned {rc}: {capi.last_error()}"
 
@@ -47,6 +62,7 @@ def decode(route, mfa, capi, q, kc, vc, lens=None, block_table=None, num_splits=
     lse_acc = torch.empty(max(S, 1), B, H, dtype=torch.float32, device=q.device)
     if S > 1:
         p.oaccum_ptr, p.softmax_lseaccum_ptr = o_acc.data_ptr(), lse_acc.data_ptr()
+        split_counters(capi, p)
     _check(capi, lib.mfa_run_flash_attention_with_kv_cache(ctypes.byref(p), _stream()))
     return (o, lse, o_acc, lse_acc, S) if return_partials else o
 

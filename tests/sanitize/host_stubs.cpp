@@ -10,10 +10,12 @@ extern "C" int mfa_test_launch_count = 0;
 
 namespace mfa {
 int launch_prefill(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
-int launch_decode(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
-int launch_kvcache_packed(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
+int launch_decode(const mfa_forward_params&, hipStream_t, bool* f) { ++mfa_test_launch_count; if (f) *f = false; return 0; }
+int launch_kvcache_packed(const mfa_forward_params&, hipStream_t, bool* f) { ++mfa_test_launch_count; if (f) *f = false; return 0; }
 int launch_decode_combine(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
 int launch_kvcache_append(const mfa_kvcache_append_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
+int xcd_premise_probe(int) { return 0; }
+bool fused_merge_pays(int64_t workgroups, int64_t pbytes) { return workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes; }
 } // namespace mfa
 
 extern "C" {
@@ -21,4 +23,5 @@ hipError_t hipGetDevice(int* d) { if (d) *d = 0; return hipErrorNoDevice; }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { if (v) *v = 0; return hipErrorNoDevice; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "stub"; }
+hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { if (s) *s = hipStreamCaptureStatusNone; return hipSuccess; }
 }

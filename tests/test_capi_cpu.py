@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(capi):
     assert {"mfa_run_flash_attention_forward", "mfa_run_flash_attention_with_kv_cache", "mfa_num_splits_heuristic"} <= set(names)
     for n in names:
         assert hasattr(lib, n), f"libmfa_hip.so does not export {n}"
-    assert lib.mfa_abi_version() == 3
+    assert lib.mfa_abi_version() == 4
     assert b"gfx950" in lib.mfa_version()
 
 
@@ -190,3 +190,12 @@ def test_kvcache_plan_without_device(capi, oracle):
     assert plan(batch=2, seqlen_q=1024, heads=32, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=8) == (1, 0, 0)
     p = _params(capi, oracle, heads=8, kv_heads=3)
     assert lib.mfa_kvcache_plan(ctypes.byref(p), None, None, None) == capi.MFA_ERR_INVALID_ARGUMENT
+    # arrival counters of the in-kernel split merge: one per (batch, KV head[, head chunk / block of 128 packed rows]) while the
+    # split launch is at most 512 workgroups; 0 = the library keeps the merge as its own launch (or nothing is split)
+    cnt = lambda **kw: lib.mfa_kvcache_counter_count(ctypes.byref(_params(capi, oracle, **kw)))
+    assert cnt(batch=4, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=8192, head_dim=128, num_splits=8) == 32
+    assert cnt(batch=4, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=8192, head_dim=128, num_splits=1) == 0
+    assert cnt(batch=24, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=8192, head_dim=128, num_splits=4) == 0   # 768 workgroups
+    assert cnt(batch=16, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=4) == 128  # vector kernel
+    assert cnt(batch=2, seqlen_q=40, heads=32, kv_heads=4, seqlen_k=4096, head_dim=128, num_splits=4) == 2 * 4 * 3  # packed rows
+    assert cnt(batch=2, seqlen_q=1024, heads=32, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=1) == 0

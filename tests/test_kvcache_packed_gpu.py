@@ -130,6 +130,25 @@ def test_c_abi_plan_and_forced_splits(capi):
         assert lib.mfa_run_flash_attention_with_kv_cache(ctypes.byref(p), stream) == 0, capi.last_error()
         torch.cuda.synchronize()
         close(o, ref, f"C ABI splits={s.value}")
+        # without counters the merge is decode_combine_kernel's launch; with the caller's counters (and mfa_init) it runs in
+        # the split kernel -- same partials, same merge function: bit-identical output, counters back at zero
+        route = lib.mfa_debug_last_route()
+        assert route & capi.MFA_ROUTE_PACKED and not route & capi.MFA_ROUTE_FUSED_MERGE
+        assert bool(route & capi.MFA_ROUTE_COMBINE_LAUNCH) == (s.value > 1)
+        if s.value > 1:
+            assert lib.mfa_kvcache_counter_count(ctypes.byref(p)) == B * Hk * ((Sq * (Hq // Hk) + 127) // 128)
+            assert lib.mfa_init(-1) == 1
+            import hip_path as hp
+            hp.split_counters(capi, p)
+            o2 = torch.full_like(q, float("nan"))
+            p.o_ptr = o2.data_ptr()
+            for _ in range(2):
+                assert lib.mfa_run_flash_attention_with_kv_cache(ctypes.byref(p), stream) == 0, capi.last_error()
+                assert lib.mfa_debug_last_route() == capi.MFA_ROUTE_PACKED | capi.MFA_ROUTE_FUSED_MERGE
+                torch.cuda.synchronize()
+                assert torch.equal(o2, o)
+            key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+            assert int(hp._COUNTERS[key].abs().sum()) == 0
 
 
 def test_strided_queries_and_caches(mfa):

@@ -90,3 +90,45 @@ def test_thread_local_errors_and_concurrent_calls(mfa, capi):
     torch.cuda.synchronize()
     assert len(errs) == 2 and all("head_dim" in e or "contiguous" in e or "multiple" in e for e in errs)
     assert all(torch.equal(o, ref) for o in outs)
+
+
+def test_graph_capture_with_and_without_split_counters(mfa, capi):
+    """The in-kernel split merge uses arrival counters that the HOST layer owns (include/mfa.h: no launch entry point
+    allocates).  (a) On a stream that has no counter buffer yet, a capture must not create one: the captured launch
+    merges through decode_combine_kernel.  (b) On a stream whose buffer exists, the captured launch merges in the kernel
+    and keeps a pointer that stays valid: after unrelated, larger split launches the replay still equals the eager call."""
+    lib = capi.load()
+    B, H, Hk, D = 2, 8, 2, 128
+    qd = rnd(B, 1, H, D, dtype=torch.bfloat16, seed=4)
+    kc, vc = rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=5), rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=6)
+    lens = torch.tensor([2000, 777], dtype=torch.int32, device=DEV)
+    call = lambda: mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=4)
+    eager = call()
+    assert lib.mfa_debug_last_route() == capi.MFA_ROUTE_DECODE | capi.MFA_ROUTE_FUSED_MERGE
+    torch.cuda.synchronize()
+    fresh, warm = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(warm):
+        call()
+    torch.cuda.synchronize()
+    graphs = []
+    for stream, want in ((fresh, capi.MFA_ROUTE_COMBINE_LAUNCH), (warm, capi.MFA_ROUTE_FUSED_MERGE)):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            o = call()
+            route = lib.mfa_debug_last_route()
+        assert route == capi.MFA_ROUTE_DECODE | want, (route, want)
+        graphs.append((g, o))
+    # other split launches in between (more rows, more splits: a library-owned buffer would have had to grow here)
+    qb = rnd(16, 1, 32, D, dtype=torch.bfloat16, seed=7)
+    kb, vb = rnd(16, 1024, 8, D, dtype=torch.bfloat16, seed=8), rnd(16, 1024, 8, D, dtype=torch.bfloat16, seed=9)
+    with torch.cuda.stream(warm):
+        mfa.flash_attn_with_kvcache(qb, kb, vb, num_splits=4)
+    torch.cuda.synchronize()
+    for seed in (21, 22):
+        qd.copy_(rnd(B, 1, H, D, dtype=torch.bfloat16, seed=seed))
+        for g, o in graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        eager = call()
+        for g, o in graphs:
+            assert torch.equal(o, eager)
