@@ -214,6 +214,16 @@ int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_
 void mfa_decode_workspace_bytes(int num_splits, int batch, int heads, int head_dim,
                                 size_t* oaccum_bytes, size_t* lse_bytes);
 
+/* TEST HOOK, not part of the drop-in surface: overrides a launch-geometry choice for the whole process so that the parity
+ * tests can drive paths a default launch does not reach on small inputs ("p64_grid", "group_pairs", "p64_no_loop",
+ * "nw8", "mq_stream", "decode_gt_max"; 0, or -1 for mq_stream, restores the library's choice).  Results never depend on
+ * a knob.  The library reads exactly three environment variables, once per process, as documented tuning switches:
+ *   MFA_PREFILL64=0|1|2      head-dim-128 dense prefill: 0 = always the general kernel, 2 = the 64-rows-per-wave kernel for
+ *                            every shape it serves (default 1: not for keys that fit three tiles);
+ *   MFA_FUSED_COMBINE=0      never merge key splits inside the split kernel (split_counters ignored);
+ *   MFA_KVCACHE_PACKED=0|1   force the kv-cache route away from / onto the packed-row kernel. */
+int mfa_test_set_knob(const char* name, int value);
+
 /* 1 while `hip_stream` is being captured into a hipGraph, 0 when not, < 0 on a HIP error (a host that owns
  * split_counters buffers must not create one during a capture). */
 int mfa_stream_is_capturing(void* hip_stream);

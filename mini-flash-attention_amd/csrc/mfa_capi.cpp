@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <utility>
 
 #include "mfa_launch.h"
 
@@ -69,7 +71,24 @@ int check_common(const mfa_forward_params* p) {
 
 } // namespace
 
+namespace mfa {
+TestKnobs g_knobs;
+}
+
 extern "C" {
+
+int mfa_test_set_knob(const char* name, int value) {
+    if (!name) return fail(MFA_ERR_INVALID_ARGUMENT, "knob name is NULL");
+    const std::pair<const char*, std::atomic<int>*> table[] = {
+        {"p64_grid", &mfa::g_knobs.p64_grid},       {"group_pairs", &mfa::g_knobs.group_pairs}, {"p64_no_loop", &mfa::g_knobs.p64_no_loop},
+        {"nw8", &mfa::g_knobs.nw8},                 {"mq_stream", &mfa::g_knobs.mq_stream},     {"decode_gt_max", &mfa::g_knobs.decode_gt_max}};
+    for (const auto& kv : table)
+        if (!std::strcmp(kv.first, name)) {
+            kv.second->store(value);
+            return MFA_OK;
+        }
+    return fail(MFA_ERR_INVALID_ARGUMENT, "unknown test knob '%s'", name);
+}
 
 int mfa_abi_version(void) { return MFA_ABI_VERSION; }
 

@@ -434,7 +434,7 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream, bool* merged_
     a.seqlen_q = 1;
     a.o_row_stride = 0;
     const int G = a.group;
-    static const int env_gtmax = [] { const char* e = getenv("MFA_DECODE_GT_MAX"); return e ? atoi(e) : 0; }();
+    const int env_gtmax = g_knobs.decode_gt_max.load();
     const int gtmax = env_gtmax > 0 ? env_gtmax : 8;
     int gt = G <= 4 ? G : (G <= 6 ? 6 : 8);
     if (G == 5) gt = 6;

@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "../../include/mfa.h"
 
 namespace mfa {
@@ -32,6 +34,19 @@ constexpr int64_t kFusedMergeMaxPartialBytes = 8 << 20;
 inline int64_t partial_bytes(const mfa_forward_params& p) { // (S, B, Sq, H, D) + (S, B, Sq, H) fp32
     return p.num_splits > 1 ? 4ll * p.num_splits * p.batch * p.seqlen_q * p.heads * (p.head_dim + 1) : 0;
 }
+
+// Test hooks (mfa_test_set_knob, include/mfa.h): launch geometry overrides that the parity tests use to drive paths a
+// default launch does not reach on small inputs.  Zero / negative = the library's own choice.  Not tuning knobs: the
+// three documented environment switches (MFA_PREFILL64, MFA_FUSED_COMBINE, MFA_KVCACHE_PACKED) are those.
+struct TestKnobs {
+    std::atomic<int> p64_grid{0};       // prefill64: persistent grid size (a multiple of 8)
+    std::atomic<int> group_pairs{0};    // prefill kernels: (batch, head) pairs per scheduling group
+    std::atomic<int> p64_no_loop{0};    // prefill64: every iteration through the per-phase blocks, never the loop block
+    std::atomic<int> nw8{0};            // general prefill kernel, head dim 128: 8-wave workgroups
+    std::atomic<int> mq_stream{-1};     // packed kv-cache kernel: non-temporal K/V policy forced off (0) / on (1)
+    std::atomic<int> decode_gt_max{0};  // vector decode: largest group tile
+};
+extern TestKnobs g_knobs;
 
 // KV-cache append (no reference counterpart: see include/mfa.h).
 int launch_kvcache_append(const mfa_kvcache_append_params& p, hipStream_t stream);

@@ -586,8 +586,8 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     a.num_m_blocks = (a.seqlen_q + BM - 1) / BM;
     const int64_t npairs = (int64_t)a.heads * a.batch;
     if (npairs <= 0 || a.num_m_blocks <= 0) return 0;
-    static const int env_gp = [] { const char* e = getenv("MFA_GROUP_PAIRS"); return e ? atoi(e) : 0; }();
-    a.group_pairs = env_gp > 0 ? env_gp : 4;
+    const int knob_gp = g_knobs.group_pairs.load();
+    a.group_pairs = knob_gp > 0 ? knob_gp : 4;
     // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
     const int64_t per_xcd = (npairs + 7) / 8;
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
@@ -614,8 +614,7 @@ static int launch_prefill_d(PrefillArgs& a, hipStream_t stream) {
     case 64: return launch_prefill_t<T, 64, 4>(a, stream);
     case 96: return launch_prefill_t<T, 96, 4>(a, stream);
     case 128: {
-        static const int env_nw = [] { const char* e = getenv("MFA_NW"); return e ? atoi(e) : 0; }();
-        return env_nw == 8 ? launch_prefill_t<T, 128, 8>(a, stream) : launch_prefill_t<T, 128, 4>(a, stream);
+        return g_knobs.nw8.load() ? launch_prefill_t<T, 128, 8>(a, stream) : launch_prefill_t<T, 128, 4>(a, stream);
     }
     case 160: return launch_prefill_t<T, 160, 4>(a, stream);
     case 192: return launch_prefill_t<T, 192, 4>(a, stream);
@@ -687,7 +686,7 @@ static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
     const int64_t total = 8 * ((npairs + 7) / 8) * a.num_splits * a.mq_row_blocks;
     if (total > 0x7fffffffLL) return -1;
     auto kern = prefill_fwd_kernel<T, D, NW, PG, true, false>;
-    static const int env_nt = [] { const char* e = getenv("MFA_MQ_STREAM"); return e ? atoi(e) : -1; }();
+    const int env_nt = g_knobs.mq_stream.load();
     if (env_nt == 1 || (env_nt != 0 && a.mq_row_blocks == 1)) kern = prefill_fwd_kernel<T, D, NW, PG, true, true>;
     if (smem > 64 * 1024 &&
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)

@@ -1,7 +1,8 @@
-"""GPU parity of the 64-rows-per-wave prefill kernel (csrc/mfa_prefill64.hip) under the launch knobs a test process cannot
-change after its first launch (they are read once): a small persistent grid (every workgroup walks many work items, ring
+"""GPU parity of the 64-rows-per-wave prefill kernel (csrc/mfa_prefill64.hip) under launch geometries a default launch
+does not reach on small inputs, set through the library's test hook (mfa_test_set_knob; the child tools apply
+MFA_TEST_KNOBS, tools/_knobs.py): a small persistent grid (every workgroup walks many work items, ring
 slots rotate across items, the snake order's odd steps), other scheduling group sizes, and the kernel driven entirely
-through its per-phase blocks (MFA_P64_DEBUG=1: the steady-state loop block never entered).  Each case is one child python
+through its per-phase blocks (p64_no_loop: the steady-state loop block never entered).  Each case is one child python
 running tools/p64_check.py (11 shapes x fp16/bf16 x causal vs SDPA-fp32, plus a ramp that forces the textbook update tile
 after tile) and tools/p64_diag.py (spikes per tile: which chain / tile a stream bug would hit)."""
 import os
@@ -22,10 +23,9 @@ def run(tool, env_extra, *args):
     return r.stdout
 
 
-@pytest.mark.parametrize("env", [{"MFA_P64_GRID": "8"}, {"MFA_P64_GRID": "24", "MFA_GROUP_PAIRS": "8"}, {"MFA_GROUP_PAIRS": "1"},
-                                 {"MFA_P64_DEBUG": "1"}], ids=lambda e: ",".join(f"{k[4:]}={v}" for k, v in e.items()))
-def test_parity_under_launch_knobs(env):
-    out = run("p64_check.py", env, "noperf")
+@pytest.mark.parametrize("knobs", ["p64_grid=8", "p64_grid=24,group_pairs=8", "group_pairs=1", "p64_no_loop=1"])
+def test_parity_under_launch_knobs(knobs):
+    out = run("p64_check.py", {"MFA_TEST_KNOBS": knobs}, "noperf")
     assert "FAILURES: 0" in out and out.count("ramp causal") == 2, out[-1500:]
 
 

@@ -2,7 +2,9 @@
 """Generates mini-flash-attention_amd/csrc/mfa_prefill64_stream.inc: the instruction streams of prefill64_kernel
 (mfa_prefill64.hip) as inline-asm blocks, one text per element type, with every vector register named physically.
 
-    python tools/gen_p64_stream.py            # rewrites the .inc (committed; build.py does not run this)
+    python tools/gen_p64_stream.py            # rewrites the .inc (committed; build.py does not run this, but
+                                              # tests/test_p64_stream_cpu.py fails when the two disagree)
+    python tools/gen_p64_stream.py --out F    # writes F instead
     python tools/gen_p64_stream.py --dev      # + mfa_prefill64_stream_dev.inc: timing-only loop variants for -DMFA_DEV_P64 builds
 
 The kernel's whole tile loop runs out of a RESERVED part of the register file that hipcc never sees as variables:
@@ -797,7 +799,12 @@ def emit_block(fh, name, lines_of, outs, ins, exclude=()):
 
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if "--help" in sys.argv or "-h" in sys.argv:
+        print(__doc__)
+        return
     path = os.path.join(root, "mini-flash-attention_amd", "csrc", "mfa_prefill64_stream.inc")
+    if "--out" in sys.argv:  # (tests/test_p64_stream_cpu.py regenerates into a temporary file and compares)
+        path = sys.argv[sys.argv.index("--out") + 1]
     KS, VS = '[kslot] "s"(kslot)', '[vslot] "s"(vslot)'
     steady_outs = ['[j] "+s"(j)', '[koff] "+s"(k_off)', '[voff] "+s"(v_off)', '[status] "=&s"(status)']
     steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[ksrd] "s"(k_srd)', '[vsrd] "s"(v_srd)', '[k16] "s"(k_step)',
@@ -842,7 +849,7 @@ def main():
         fh.write('#define P64_FINAL_F16 ""\n#define P64_FINAL_BF16 ""\n')
         fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
                  " : : \"memory\"\n")
-    print("wrote", os.path.relpath(path, root))
+    print("wrote", os.path.relpath(path, root) if "--out" not in sys.argv else path)
     if "--dev" in sys.argv:
         # timing-only variants of the steady loop (results are wrong): developer builds (-DMFA_DEV_P64), MFA_P64_DEBUG >> 2 = 1 + index
         dev = os.path.join(root, "mini-flash-attention_amd", "csrc", "mfa_prefill64_stream_dev.inc")

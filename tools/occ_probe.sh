@@ -3,7 +3,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp; cd /tmp
 S=${1:-1024}; C=${2:-1}
 for g in ${3:-1 4}; do
-  export MFA_GROUP_PAIRS=$g
+  export MFA_TEST_KNOBS=group_pairs=$g
   OUT=$ROOT/gpurun_out/occ_$g; rm -rf $OUT; mkdir -p $OUT
   rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --kernel-trace --output-format csv -d $OUT -- python3 $ROOT/tools/run_shape.py prefill $S $C 4 > $OUT/log.txt 2>&1
   python3 - $OUT $g <<'PY'

@@ -3,6 +3,8 @@ import torch
 os.environ.setdefault("MFA_PREFILL64", "2")  # every shape the 64-row kernel serves goes to it
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs; _knobs.apply()
 import torch.nn.functional as F
 from torch.nn.attention import SDPBackend, sdpa_kernel
 def ref(q, k, v, causal):

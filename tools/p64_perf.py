@@ -19,6 +19,8 @@ if os.environ.get("P64_PERF_CHILD") != "1":
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs; _knobs.apply()
 B, H, D = 48, 24, 128
 for S in (1024, 2048, 4096):
     q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3))

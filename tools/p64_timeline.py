@@ -15,6 +15,8 @@ os.environ["MFA_P64_DBGPTR"] = str(dbg.data_ptr())
 os.environ["MFA_P64_DEBUG"] = str(2 | (int(sys.argv[3]) if len(sys.argv) > 3 else 0))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs; _knobs.apply()
 q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3))
 for _ in range(5):
     mfa.flash_attn_func(q, k, v, causal=causal)

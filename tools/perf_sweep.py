@@ -9,7 +9,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.environ.get("MFA_PKG_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
-import mini_flash_attention as mfa  # noqa: E402
+import mini_flash_attention as mfa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs; _knobs.apply()  # noqa: E402
 
 
 def measure(fn, warmup=5, iters=20):
