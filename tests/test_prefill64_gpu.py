@@ -29,13 +29,14 @@ def test_parity_under_launch_knobs(knobs):
     assert "FAILURES: 0" in out and out.count("ramp causal") == 2, out[-1500:]
 
 
-def test_textbook_update_tile_by_tile():
-    out = run("p64_diag.py", {})
+@pytest.mark.parametrize("knobs", ["", "p64_grid=8", "p64_grid=8,p64_no_loop=1"])
+def test_textbook_update_tile_by_tile(knobs):
+    out = run("p64_diag.py", {"MFA_TEST_KNOBS": knobs})
     for line in out.splitlines():
         if " max " in line:
             worst = float(line.split(" max ")[1].split()[0])
             assert worst < 2e-3, line
-    assert out.count("spike tile") >= 7 and "ramp causal" in out
+    assert out.count("spike tile") >= 14 and "ramp causal" in out and "multi ramp down causal" in out
 
 
 def test_bit_determinism():

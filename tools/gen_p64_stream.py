@@ -87,7 +87,7 @@ NW = 4
 NI = 16 // NW
 LIMIT = 0x44800000  # 1024.0f
 NEG_INF = 0xFF800000
-NV, NA = 180, 208    # reserved VGPRs / AGPRs
+NV, NA = 184, 208    # reserved VGPRs / AGPRs
 VB, AB = 72, 48      # first reserved VGPR / AGPR
 
 
@@ -136,6 +136,14 @@ def M(c):
 
 def TMP(c, i):  # three temporaries per chain
     return 174 + 3 * c + i
+
+
+def LOLD(c):  # l / m of the work item whose epilogue is still to run (P64_SAVE_LM: the next item's first tile overwrites l, m)
+    return 180 + c
+
+
+def MOLD(c):
+    return 182 + c
 
 
 def O_BASE(c, d):
@@ -301,9 +309,9 @@ class Stream:
             if dma:
                 pc = f // 2
                 if pc < NI:
-                    self.e(f"s_add_u32 m0, %[dst0], {((i + 2) % 3) * TILE + pc * NW * 1024}")
+                    self.e(f"s_add_u32 m0, %[dst0], {((i + 2) % 3) * TILE + (NI - 1 - pc) * NW * 1024}")
                 else:
-                    self.e(f"s_add_u32 m0, %[dst0], {V_RING + ((i + 1) % 3) * TILE + (pc - NI) * NW * 1024}")
+                    self.e(f"s_add_u32 m0, %[dst0], {V_RING + ((i + 1) % 3) * TILE + (2 * NI - 1 - pc) * NW * 1024}")
             if t == 0 and "sm" not in self.ablate:  # the sums of tile j-1 (accepted at the end of the last iteration)
                 for c2 in range(2):
                     self.e(f"v_add_f32 {vr(L(c2))}, {vr(L(c2))}, {vr(LT(c2))}")
@@ -315,10 +323,10 @@ class Stream:
             if dma:
                 if pc < NI:
                     self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, %[ksrd], %[koff] offen lds")
-                    self.e("s_add_u32 %[koff], %[koff], %[k16]")
+                    self.e("s_sub_u32 %[koff], %[koff], %[k16]")
                 else:
                     self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, %[vsrd], %[voff] offen lds")
-                    self.e("s_add_u32 %[voff], %[voff], %[v16]")
+                    self.e("s_sub_u32 %[voff], %[voff], %[v16]")
         # ---- phase X: S^T = K.Q^T of tile j+1 into the buffer P^1 (slot t: chain t & 1, K fragment t >> 1 = 8*kb + ks)
         for t in range(32):
             ch, f = t & 1, t >> 1
@@ -416,7 +424,9 @@ class Stream:
         self.pads()
         return self.out
 
-    def phase_y(self, PP, sm):
+    def phase_y(self, PP, sm, fill=None):
+        fill = list(fill or [])
+        share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
         self.lds_log = []
         self.pads()
         for d in range(4):
@@ -428,9 +438,10 @@ class Stream:
             ch, f = t & 1, t >> 1
             self.mfma_y(PP, t)
             if ch == 1 and f < 15:
-                self.wait_frag("V", 0, f + 1, pad=not sm)
+                self.wait_frag("V", 0, f + 1, pad=not sm and len(share[t]) < 3)
             if sm:
                 self.sm_step(PP ^ 1, t)
+            self.out += share[t]
             if f + PF <= 15:
                 self.v_read_half(f + PF, ch)
         for d in range(4):
@@ -566,6 +577,9 @@ class Stream:
         self.e("s_nop 1")
         self.e(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")  # max of the raw scores over the row's 64 keys
         if first:
+            # (walking the tiles downwards, a row's first tile may hold no key it sees -- a causal offset that is not a
+            # multiple of 64: keep m finite; the row's next tile then fails the sum test and takes the textbook update)
+            self.e(f"v_max_f32 {vr(t0)}, 0xf149f2ca, {vr(t0)}")  # -1e30
             self.e(f"v_mov_b32 {vr(M(ch))}, {vr(t0)}")
         else:
             self.e(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(M(ch))}")  # m_new (a fully masked tile leaves m)
@@ -597,10 +611,28 @@ class Stream:
         lines, self.out = self.out, out
         return lines
 
-    def first_lines(self, P):
-        """the first tile's textbook softmax, the two chains' instructions alternating (independent dependency chains)"""
+    def mask_lines(self, P, ch):
+        out, self.out = self.out, []
+        self.mask_chain(P, ch)
+        lines, self.out = self.out, out
+        return lines
+
+    def first_lines(self, P, masked=False):
+        """the first tile's textbook softmax (behind its mask, if any), the two chains' instructions alternating
+        (independent dependency chains)"""
         a, b = self.exact_softmax(P, 0, True), self.exact_softmax(P, 1, True)
-        return [x for pair in zip(a, b) for x in pair]
+        assert len(a) == len(b)
+        # (the mask's compare / select pairs go through VCC: never interleaved with another chain's)
+        mask = self.mask_lines(P, 0) + self.mask_lines(P, 1) if masked else []
+        return mask + [x for pair in zip(a, b) for x in pair]
+
+    def save_lm_lines(self):
+        """l, m of the item that has just seen its last tile -> LOLD / MOLD (its epilogue reads them there), l := 0 for the
+        next item's first tile"""
+        lines = []
+        for c in range(2):
+            lines += [f"v_mov_b32 {vr(LOLD(c))}, {vr(L(c))}", f"v_mov_b32 {vr(MOLD(c))}, {vr(M(c))}", f"v_mov_b32 {vr(L(c))}, 0"]
+        return lines
 
     def mask_block(self, P):
         self.pads()
@@ -615,9 +647,32 @@ class Stream:
         self.e("s_nop 4")
         return self.out
 
-    def x_first_block(self):
-        """phase X of tile 1 (slot %[kslot], buffer 1) with the textbook softmax of tile 0 (buffer 0) in its gaps"""
-        return self.phase_x(1, False, fill=self.first_lines(0))
+    def xn_block(self, pn):
+        """phase X alone: scores of the K tile in slot %[kslot] into buffer pn (a work item's first tile)"""
+        return self.phase_x(pn, False)
+
+    def xf_block(self, pn, masked):
+        """phase X of a wave's second tile (slot %[kslot]) into buffer pn with the textbook softmax of its first tile
+        (buffer pn^1; masked: behind that tile's mask, %[skm1], %[j64]) in the gaps"""
+        return self.phase_x(pn, False, fill=self.first_lines(pn ^ 1, masked))
+
+    def bndb_block(self, pn, masked):
+        """The iteration that joins two work items, for a wave that takes part in both without a gap: tile g (parity pn) is
+        the NEW item's first tile.  Phase Y: P.V of the OLD item's last tile (P in buffer pn^1, V tile in slot %[vslot]);
+        phase X: scores of the new item's second tile (slot %[kslot]) into buffer pn^1; in their gaps l, m of the old item
+        -> LOLD / MOLD and the textbook softmax of tile g (buffer pn; masked: behind its mask).  The old item's epilogue
+        (P64_EPILOGUE*) follows this block."""
+        lines = self.save_lm_lines() + self.first_lines(pn, masked)
+        n1 = len(lines) // 2
+        self.phase_y(pn ^ 1, False, fill=lines[:n1])
+        self.phase_x(pn ^ 1, False, fill=lines[n1:])
+        return self.out
+
+    def save_lm_block(self):
+        self.pads()
+        self.out += self.save_lm_lines()
+        self.e("s_nop 4")
+        return self.out
 
     def check_block(self):
         """status bit c = chain c failed the test of its tile sum; passing chains: l += lt"""
@@ -662,25 +717,29 @@ class Stream:
             self.e("s_add_u32 %[off], %[off], %[step]")
         return self.out
 
-    def epilogue_block(self):
+    def epilogue_block(self, pn):
         """O / l of both chains -> global memory as whole rows (reference prefill.cuh:600-612): 1/l (1 for a row without
         keys), pack, this wave's LDS staging area (32 rows of 272 bytes, one chain at a time), rows back as 16-byte
-        pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped).
+        pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped); then O := 0 for the next item.
+        Runs BETWEEN two work items, possibly after the next item's first softmax: l comes from LOLD, and the only
+        temporaries are registers that hold nothing of the next item -- the V fragment ring, the chain temporaries and the
+        upper halves of buffer pn's 16-register blocks (packed P sits in the lower halves; buffer pn^1 holds raw scores).
         %[wr] = stage + r*272 + 8h, %[rd] = stage + (lane/16)*272 + 16*(lane%16), %[ovoff] = (first row of the wave +
         lane/16) * row bytes + 16*(lane%16), %[osb4] = 4 rows in bytes"""
-        T = lambda i: S_BASE(0, 0) + i  # temporaries: the S buffers are free now
-        inv = [T(0), T(1)]
+        X = lambda n: VFR(n % 4)                                            # pack groups: 4 x 4 registers
+        R = lambda it: S_BASE(pn, it >> 2) + 16 * ((it >> 1) & 1) + 8 + 4 * (it & 1)  # row pieces: 8 x 4 registers
+        inv = [TMP(0, 0), TMP(1, 0)]
         self.pads()
         for ch in range(2):
-            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
-            self.e(f"v_mov_b32 {vr(t0)}, {vr(L(ch))}")
-            self.e(f"v_mov_b32 {vr(t1)}, {vr(L(ch))}")
+            t0, t1 = TMP(ch, 1), TMP(ch, 2)
+            self.e(f"v_mov_b32 {vr(t0)}, {vr(LOLD(ch))}")
+            self.e(f"v_mov_b32 {vr(t1)}, {vr(LOLD(ch))}")
         self.e("s_nop 1")
         for ch in range(2):
-            self.e(f"v_permlane32_swap_b32 {vr(T(2 + 2 * ch))}, {vr(T(3 + 2 * ch))}")
+            self.e(f"v_permlane32_swap_b32 {vr(TMP(ch, 1))}, {vr(TMP(ch, 2))}")
         self.e("s_nop 1")
         for ch in range(2):
-            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
+            t0, t1 = TMP(ch, 1), TMP(ch, 2)
             self.e(f"v_add_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
             self.e(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
             self.e(f"v_cmp_lt_f32 vcc, 0, {vr(t0)}")
@@ -693,8 +752,8 @@ class Stream:
             n = 0
             for d in range(4):
                 for g4 in range(4):
-                    x = T(8 + 4 * (n % 8))
-                    n += 1
+                    x = X(n)
+                    n += 1  # (a group's registers are free again once its ds_write has issued: LDS reads its operands at issue)
                     for i in range(4):
                         self.e(f"v_accvgpr_read_b32 {vr(x + i)}, {ar(O_BASE(ch, d) + 4 * g4 + i)}")
                     for i in range(4):
@@ -703,29 +762,51 @@ class Stream:
                     self.e(f"{self.cvt} {vr(x + 1)}, {vr(x + 2)}, {vr(x + 3)}")
                     self.e(f"ds_write_b64 %[wr], {vr(x, 2)} offset:{16 * (4 * d + g4)}")
             self.e("s_waitcnt lgkmcnt(0)")
-            R = lambda it: T(48 + 4 * it)
             for it in range(8):
                 self.e(f"ds_read_b128 {vr(R(it), 4)}, %[rd] offset:{it * 4 * 272}")
             for it in range(8):
                 self.e(f"s_waitcnt lgkmcnt({7 - it})")
                 self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen")
                 self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[osb4]")
+        for i in range(128):
+            self.e(f"v_accvgpr_write_b32 {ar(i)}, 0")
+        self.pads()
         return self.out
 
     def init_lines(self):
         lines = [f"v_accvgpr_write_b32 {ar(i)}, 0" for i in range(128)]
-        lines += [f"v_mov_b32 {vr(r)}, 0" for r in (L(0), L(1), LT(0), LT(1), M(0), M(1), MC(0), MC(1))]
+        lines += [f"v_mov_b32 {vr(r)}, 0" for r in (L(0), L(1), LT(0), LT(1), M(0), M(1), MC(0), MC(1), LOLD(0), LOLD(1), MOLD(0), MOLD(1))]
         return lines
+
+    def init_block(self):
+        """once per workgroup: O, l, m := 0"""
+        self.pads()
+        self.out += self.init_lines()
+        self.pads()
+        return self.out
+
+    def qhi_block(self):
+        """a work item's mask bounds (row + hi of this lane's row in chain 0 / 1) -> home registers"""
+        for c in range(2):
+            self.e(f"v_mov_b32 {vr(QHI(c))}, %[qhi{c}]")
+        self.e("s_nop 1")
+        return self.out
+
+    def q_global_block(self):
+        """Q fragments of a work item straight from global memory -> home registers (the rarely-run way back to an item's Q
+        after the next item's has replaced it: P64_REDO* in the iteration that already carries the next item's first
+        scores).  %[qv] = r * row bytes + 16 h, %[q32] = 32 rows in bytes, %[srd]: descriptor of the wave's rows"""
+        for c in range(2):
+            self.e(f"s_mov_b32 s{S_T0}, 0" if c == 0 else f"s_mov_b32 s{S_T0}, %[q32]")
+            for ks in range(8):
+                self.e(f"buffer_load_dwordx4 {ar(Q_BASE(c, ks), 4)}, %[qv], %[srd], s{S_T0} offen offset:{ks * 32}")
+        self.e("s_waitcnt vmcnt(0)")
+        self.pads()
+        return self.out
 
     def setup_block(self):
         self.e("s_nop 0")
         return self.out
-
-    def x0_block(self):
-        """a new work item: phase X of its tile 0 (slot %[kslot]) into buffer 0; O, l := 0 and the item's mask bounds
-        (%[qhi0], %[qhi1]) -> home registers in its gaps.  Q is in its home registers (P64_Q_LDS)."""
-        lines = self.init_lines() + [f"v_mov_b32 {vr(QHI(c))}, %[qhi{c}]" for c in range(2)]
-        return self.phase_x(0, False, fill=lines)
 
     def dma_q_block(self):
         """the wave's 64 Q rows of a work item -> its LDS Q buffer, as a K-tile-shaped image (16 pieces of 4 rows; row i at
@@ -743,8 +824,9 @@ class Stream:
     def q_lds_block(self):
         """Q fragments (B operand of S^T = K.Q^T: row, columns 16*ks + 8h .. +7, as stored; the scale is applied to the
         fp32 scores) from the wave's LDS Q buffer -> home registers.  The image is K-tile-shaped, so the K read addresses
-        serve: %[qoff] = the buffer's offset from the K ring's slot 0.  Run between two work items (S buffers free)."""
-        T = lambda i: S_BASE(0, 0) + i
+        serve: %[qoff] = the buffer's offset from the K ring's slot 0.  Runs at the top of an item's last iteration (both S
+        buffers are live there): the address temporaries are the V fragment ring, idle between two iterations."""
+        T = lambda i: VFR(0) + i
         for ks in range(8):
             self.e(f"v_add_u32 {vr(T(ks))}, %[qoff], {vr(KRD(ks))}")
         for c in range(2):
@@ -819,35 +901,42 @@ def main():
         fixed_regs = (rng("v", KRD(0), 8) + rng("v", VRD(0), 4) + rng("v", V_KGO, 2) + rng("v", QGO[0], 2) +
                       rng("v", QGO[2], 2) + rng("v", H4, 1))
         emit_block(fh, "P64_SETUP", lambda st: st.setup_block(), [], fixed_ins, exclude=fixed_regs)
+        emit_block(fh, "P64_INIT", lambda st: st.init_block(), [], [])
+        emit_block(fh, "P64_QHI", lambda st: st.qhi_block(), [], ['[qhi0] "v"(qhi0)', '[qhi1] "v"(qhi1)'])
         emit_block(fh, "P64_DMA_Q", lambda st: st.dma_q_block(), ['[off] "+s"(dma_off)'],
                    ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
         emit_block(fh, "P64_Q_LDS", lambda st: st.q_lds_block(), [], ['[qoff] "s"(q_lds_off)'])
-        emit_block(fh, "P64_X0", lambda st: st.x0_block(), [], [KS, '[qhi0] "v"(qhi0)', '[qhi1] "v"(qhi1)'])
-        emit_block(fh, "P64_FIRST0", lambda st: st.first_block(0), [], [C_OP])
-        emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [], [KS, C_OP])
+        emit_block(fh, "P64_Q_GLOBAL", lambda st: st.q_global_block(), [], ['[qv] "v"(q_voff)', '[q32] "s"(q_step32)', '[srd] "s"(dma_srd)'])
+        emit_block(fh, "P64_SAVE_LM", lambda st: st.save_lm_block(), [], [])
         emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
+        MS = ['[skm1] "s"(skm1)', '[j64] "s"(j64)']
         for pn in range(2):
+            emit_block(fh, f"P64_XN{pn}", lambda st, pn=pn: st.xn_block(pn), [], [KS])
+            emit_block(fh, f"P64_XF{pn}", lambda st, pn=pn: st.xf_block(pn, False), [], [KS, C_OP])
+            emit_block(fh, f"P64_XF{pn}_M", lambda st, pn=pn: st.xf_block(pn, True), [], [KS, C_OP] + MS)
+            emit_block(fh, f"P64_FIRST{pn}", lambda st, pn=pn: st.first_block(pn), [], [C_OP])
+            emit_block(fh, f"P64_BNDB{pn}", lambda st, pn=pn: st.bndb_block(pn, False), [], [KS, VS, C_OP])
+            emit_block(fh, f"P64_BNDB{pn}_M", lambda st, pn=pn: st.bndb_block(pn, True), [], [KS, VS, C_OP] + MS)
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
             emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [], [VS, C_OP])
             emit_block(fh, f"P64_LAST{pn}", lambda st, pn=pn: st.last_block(pn, False), ['[status] "=&s"(status)'], [VS, C_OP])
             emit_block(fh, f"P64_LAST{pn}_M", lambda st, pn=pn: st.last_block(pn, True), ['[status] "=&s"(status)'],
-                       [VS, C_OP, '[skm1] "s"(skm1)', '[j64] "s"(j64)'])
-            emit_block(fh, f"P64_SM2_{pn}", lambda st, pn=pn: st.sm_second_half(pn), [], [C_OP])
-            emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], ['[skm1] "s"(skm1)', '[j64] "s"(j64)'])
+                       [VS, C_OP] + MS)
+            emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], MS)
             for ch in range(2):
-                emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [],
-                           ['[skm1] "s"(skm1)', '[j64] "s"(j64)', KS, C_OP])
+                emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [], MS + [KS, C_OP])
+            emit_block(fh, f"P64_EPILOGUE{pn}", lambda st, pn=pn: st.epilogue_block(pn), [],
+                       ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[osb4] "s"(o_step)'],
+                       exclude=rng("v", LOLD(0), 2) + rng("v", MOLD(0), 2))
         emit_block(fh, "P64_CHECK", lambda st: st.check_block(), ['[status] "=&s"(status)'], [])
         for nm, isv in (("P64_DMA_K", False), ("P64_DMA_V", True)):
             emit_block(fh, nm, lambda st, isv=isv: st.dma_block(isv), ['[off] "+s"(dma_off)'],
                        ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
-        emit_block(fh, "P64_EPILOGUE", lambda st: st.epilogue_block(), [],
-                   ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[osb4] "s"(o_step)'],
-                   exclude=rng("v", L(0), 2) + rng("v", M(0), 2))
-        # home registers -> operands: an empty statement whose outputs are pinned to the homes
+        # home registers -> operands: an empty statement whose outputs are pinned to the homes (l, m of the item whose epilogue
+        # has just run)
         fh.write('#define P64_FINAL_F16 ""\n#define P64_FINAL_BF16 ""\n')
-        fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
+        fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", LOLD(0), 2, "=") + "(l2)", pin("v", MOLD(0), 2, "=") + "(m2)"]) +
                  " : : \"memory\"\n")
     print("wrote", os.path.relpath(path, root) if "--out" not in sys.argv else path)
     if "--dev" in sys.argv:

@@ -26,9 +26,30 @@ run("plain", q, k, v)
 # spike: keys of ONE tile t get a big boost along q-mean direction for all rows
 d = torch.ones(128, device="cuda").half()
 qq = q.clone(); qq[..., :] = (q.float() * 0.2 + 1.0).half()      # all rows have positive projection on d
-for t in (1, 2, 3, 4, 5, 6, 7):
+for t in (0, 1, 2, 3, 4, 5, 6, 7):
     kk = k.clone(); kk[0, 64 * t: 64 * t + 64] += 1.5 * d
     run(f"spike tile {t}", qq, kk, v)
 kk = k.clone(); kk[0] += (torch.arange(S, device="cuda").view(S, 1, 1) / 40.0).half() * d
 run("ramp", qq, kk, v)
 run("ramp causal", qq, kk, v, True)
+# several (batch, head) pairs: with a small persistent grid (MFA_TEST_KNOBS=p64_grid=8) every workgroup walks a few work items
+# and the textbook update of an item's LAST iteration (tile 0: the keys are walked downwards) runs while the Q registers
+# already hold the next item's rows
+B, H = 2, 8
+q = torch.randn(B, S, H, 128, device="cuda").half()
+k = torch.randn(B, S, H, 128, device="cuda").half()
+v = torch.randn(B, S, H, 128, device="cuda").half()
+qq = (q.float() * 0.2 + 1.0).half()
+def run_multi(name, q, k, v, causal=False):
+    o = mfa.flash_attn_func(q, k, v, causal=causal)
+    err = (o.float() - ref(q, k, v, causal)).abs()
+    print(name, "max", f"{err.max().item():.2e}", "per (batch, head):", " ".join(f"{x:.1e}" for x in err.amax(dim=(1, 3)).flatten().tolist()), flush=True)
+for t in (0, 1, 7):
+    kk = k.clone(); kk[:, 64 * t: 64 * t + 64] += 1.5 * d
+    run_multi(f"multi spike tile {t}", qq, kk, v)
+    run_multi(f"multi spike tile {t} causal", qq, kk, v, True)
+kk = k.clone(); kk += (torch.arange(S, device="cuda").view(1, S, 1, 1) / 40.0).half() * d
+run_multi("multi ramp up", qq, kk, v)
+kk = k.clone(); kk += ((S - 1 - torch.arange(S, device="cuda")).view(1, S, 1, 1) / 40.0).half() * d
+run_multi("multi ramp down", qq, kk, v)
+run_multi("multi ramp down causal", qq, kk, v, True)
