@@ -159,6 +159,7 @@ def KFR(k):
 
 
 S_T0 = 84  # scalar temporary
+KSRD, VSRD = 88, 92  # P64_STEADY: the K / V buffer descriptors live in s[88:91] / s[92:95] (set from operands at entry)
 
 
 def vr(lo, n=1):
@@ -177,6 +178,7 @@ class Stream:
         self.mf = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.lds_log = []
+        self._e_ops = 0
         self.ablate = set()  # developer timing builds: "dma", "sm", "lds" leave that part of the steady loop out
 
     def e(self, s):
@@ -253,6 +255,18 @@ class Stream:
         if pad:
             self.e("s_nop 3")
 
+    def fill_line(self, ln):
+        """one line of a phase's `fill` list.  LDS operations among them are logged like the phase's own fragment reads, and
+        "@wait n" (all of the fill's LDS operations up to its n-th have completed) becomes a counted wait over both."""
+        if ln.startswith("@wait "):
+            last = max(i for i, t in enumerate(self.lds_log) if t == ("E", int(ln.split()[1])))
+            self.e(f"s_waitcnt lgkmcnt({len(self.lds_log) - 1 - last})")
+            return
+        if ln.startswith("ds_"):
+            self.lds_log.append(("E", self._e_ops))
+            self._e_ops += 1
+        self.e(ln)
+
     def filler(self):
         for tag in self.ablate:
             if tag.startswith("fill"):
@@ -292,6 +306,32 @@ class Stream:
         if "bar" not in self.ablate:
             self.e("s_waitcnt vmcnt(0)")
             self.e("s_barrier")
+        self.e(f"6{i}:")
+        # The work item's last two iterations, jsw and jsw + 1, request the NEXT item's first tiles: K from iteration jsw on
+        # (K(j+2)), V from jsw + 1 on (V(j+1)) -- new offsets and descriptor lengths, same base -- and iteration jsw + 1 runs
+        # phase X on the next item's Q rows: LDS Q buffer (%[qoff] = its offset from the K ring's slot 0; 0: no such rows) ->
+        # Q registers, idle during phase Y.  The extra LDS reads are drained here: the counted waits below stay valid.
+        self.e("s_cmp_lt_i32 %[j], %[jsw]")
+        self.e(f"s_cbranch_scc1 4{i}f")
+        self.e("s_cmp_lg_u32 %[j], %[jsw]")
+        self.e(f"s_cbranch_scc1 5{i}f")
+        self.e("s_mov_b32 %[koff], %[koff2]")
+        self.e(f"s_mov_b32 s{KSRD + 2}, %[knrec2]")
+        self.e(f"s_branch 4{i}f")
+        self.e(f"5{i}:")
+        self.e("s_mov_b32 %[voff], %[voff2]")
+        self.e(f"s_mov_b32 s{VSRD + 2}, %[vnrec2]")
+        self.e("s_cmp_eq_u32 %[qoff], 0")
+        self.e(f"s_cbranch_scc1 4{i}f")
+        for ks0 in (0, 6):
+            n = min(6, 8 - ks0)
+            for k in range(n):
+                self.e(f"v_add_u32 {vr(TMP(0, 0) + k)}, %[qoff], {vr(KRD(ks0 + k))}")
+            for c in range(2):
+                for k in range(n):
+                    self.e(f"ds_read_b128 {ar(Q_BASE(c, ks0 + k), 4)}, {vr(TMP(0, 0) + k)} offset:{c * 32 * 256}")
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e(f"4{i}:")
         # ---- phase Y: O^T += V^T.P^T of tile j-1 (slot t: chain t & 1, V fragment t >> 1 = 4*s16 + d).  The wait for a
         # fragment sits behind the MFMA of the slot before its first use (that slot's fillers separate it from the
         # consumer).  Fragment f + PF is read into the ring entry fragment f - 1 has left: its low half behind the first
@@ -322,10 +362,10 @@ class Stream:
                 self.k_read(f + PF - 16, 1, ks_)
             if dma:
                 if pc < NI:
-                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, %[ksrd], %[koff] offen lds")
+                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, s[{KSRD}:{KSRD + 3}], %[koff] offen lds")
                     self.e("s_sub_u32 %[koff], %[koff], %[k16]")
                 else:
-                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, %[vsrd], %[voff] offen lds")
+                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, s[{VSRD}:{VSRD + 3}], %[voff] offen lds")
                     self.e("s_sub_u32 %[voff], %[voff], %[v16]")
         # ---- phase X: S^T = K.Q^T of tile j+1 into the buffer P^1 (slot t: chain t & 1, K fragment t >> 1 = 8*kb + ks)
         for t in range(32):
@@ -360,6 +400,11 @@ class Stream:
         self.e("s_mov_b32 %[status], 0")
         self.e("s_cmp_ge_i32 %[j], %[jend]")
         self.e("s_cbranch_scc1 9f")
+        for base, lo, hi, nrec in ((KSRD, "kb0", "kb1", "knrec"), (VSRD, "vb0", "vb1", "vnrec")):
+            self.e(f"s_mov_b32 s{base}, %[{lo}]")
+            self.e(f"s_mov_b32 s{base + 1}, %[{hi}]")
+            self.e(f"s_mov_b32 s{base + 2}, %[{nrec}]")
+            self.e(f"s_mov_b32 s{base + 3}, 0x20000")
         self.pads()
         for i in range(1, 6):
             self.e(f"s_cmp_eq_u32 %[entry], {i}")
@@ -372,7 +417,19 @@ class Stream:
             for c2 in range(2):
                 self.e(f"v_mov_b32 {vr(LT(c2))}, 0")
             self.wait_frag("V", 0, 0, pad=True)
-            self.e(f"s_branch 1{i}f")
+            # %[relax] = 16 / 32: the wave's 16 / 32 youngest memory operations (the old item's O stores, the next item's Q
+            # requests, issued after the last tile requests) need not have completed at this iteration's barrier
+            self.e("s_cmp_lt_u32 %[relax], 16")
+            self.e(f"s_cbranch_scc1 1{i}f")
+            self.e("s_cmp_lt_u32 %[relax], 32")
+            self.e(f"s_cbranch_scc1 3{i}f")
+            self.e("s_waitcnt vmcnt(32)")
+            self.e("s_barrier")
+            self.e(f"s_branch 6{i}f")
+            self.e(f"3{i}:")
+            self.e("s_waitcnt vmcnt(16)")
+            self.e("s_barrier")
+            self.e(f"s_branch 6{i}f")
         for i in range(6):
             self.iteration(i)
         self.e("s_branch 10b")
@@ -395,6 +452,7 @@ class Stream:
         fill = list(fill or [])
         share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
         self.lds_log = []
+        self._e_ops = 0
         self.pads()
         if slot is None:
             for ks in range(8):
@@ -413,7 +471,8 @@ class Stream:
                 self.wait_frag("K", 0, f + 1, pad=not sm and len(share[t]) < 3)
             if sm:
                 self.sm_step(PN ^ 1, 32 + t)
-            self.out += share[t]
+            for ln in share[t]:
+                self.fill_line(ln)
             if ch == 0 and f + PF <= 15:
                 self.k_read(f + PF, 0, slot)
         if sm:
@@ -428,6 +487,7 @@ class Stream:
         fill = list(fill or [])
         share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
         self.lds_log = []
+        self._e_ops = 0
         self.pads()
         for d in range(4):
             self.e(f"v_add_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
@@ -441,7 +501,8 @@ class Stream:
                 self.wait_frag("V", 0, f + 1, pad=not sm and len(share[t]) < 3)
             if sm:
                 self.sm_step(PP ^ 1, t)
-            self.out += share[t]
+            for ln in share[t]:
+                self.fill_line(ln)
             if f + PF <= 15:
                 self.v_read_half(f + PF, ch)
         for d in range(4):
@@ -617,14 +678,19 @@ class Stream:
         lines, self.out = self.out, out
         return lines
 
-    def first_lines(self, P, masked=False):
+    def first_lines(self, P, masked=False, part="AB"):
         """the first tile's textbook softmax (behind its mask, if any), the two chains' instructions alternating
-        (independent dependency chains)"""
+        (independent dependency chains).  part "A": mask, row maximum, m and -m*c only; "B": the rest (exponentials, sums,
+        packing, l) -- a wave that joins an item late does A right behind the tile's scores, in an iteration it otherwise idles
+        in, and B in the shadow of its second tile's scores."""
         a, b = self.exact_softmax(P, 0, True), self.exact_softmax(P, 1, True)
         assert len(a) == len(b)
+        cut = 1 + max(i for i, ln in enumerate(a) if ln.startswith("v_sub_f32 " + vr(MC(0)) + ","))
+        assert b[cut - 1].startswith("v_sub_f32 " + vr(MC(1)) + ",")
+        lo, hi = (0 if "A" in part else cut), (len(a) if "B" in part else cut)
         # (the mask's compare / select pairs go through VCC: never interleaved with another chain's)
-        mask = self.mask_lines(P, 0) + self.mask_lines(P, 1) if masked else []
-        return mask + [x for pair in zip(a, b) for x in pair]
+        mask = self.mask_lines(P, 0) + self.mask_lines(P, 1) if masked and "A" in part else []
+        return mask + [x for pair in zip(a[lo:hi], b[lo:hi]) for x in pair]
 
     def save_lm_lines(self):
         """l, m of the item that has just seen its last tile -> LOLD / MOLD (its epilogue reads them there), l := 0 for the
@@ -651,6 +717,32 @@ class Stream:
         """phase X alone: scores of the K tile in slot %[kslot] into buffer pn (a work item's first tile)"""
         return self.phase_x(pn, False)
 
+    def xna_block(self, pn, masked):
+        """phase X alone (scores of the K tile in slot %[kslot] into buffer pn: a wave's first tile), then that tile's mask
+        (masked) and the first part of its textbook softmax (row maximum, m, -m*c) right behind"""
+        self.phase_x(pn, False)
+        self.out += self.first_lines(pn, masked, "A")
+        # P of the tile "before" the wave's first := 0 (the packed halves of buffer pn^1): the wave's next iteration can then be
+        # an ordinary one of the loop block -- P.V of that empty tile adds nothing, the softmax of the first tile runs with the
+        # m just set (its sums cannot fail the test) -- instead of a block of its own that the other waves wait for
+        for ch in range(2):
+            for kb in range(2):
+                for i in range(8):
+                    self.e(f"v_mov_b32 {vr(S_BASE(pn ^ 1, ch) + 16 * kb + i)}, 0")
+        self.e("s_nop 4")
+        return self.out
+
+    def xfb_block(self, pn):
+        """phase X of a wave's second tile (slot %[kslot]) into buffer pn with the second part of its first tile's textbook
+        softmax (buffer pn^1, after P64_XNA*) in the gaps"""
+        return self.phase_x(pn, False, fill=self.first_lines(pn ^ 1, False, "B"))
+
+    def firstb_block(self, pn):
+        self.pads()
+        self.out += self.first_lines(pn, False, "B")
+        self.e("s_nop 4")
+        return self.out
+
     def xf_block(self, pn, masked):
         """phase X of a wave's second tile (slot %[kslot]) into buffer pn with the textbook softmax of its first tile
         (buffer pn^1; masked: behind that tile's mask, %[skm1], %[j64]) in the gaps"""
@@ -660,12 +752,11 @@ class Stream:
         """The iteration that joins two work items, for a wave that takes part in both without a gap: tile g (parity pn) is
         the NEW item's first tile.  Phase Y: P.V of the OLD item's last tile (P in buffer pn^1, V tile in slot %[vslot]);
         phase X: scores of the new item's second tile (slot %[kslot]) into buffer pn^1; in their gaps l, m of the old item
-        -> LOLD / MOLD and the textbook softmax of tile g (buffer pn; masked: behind its mask).  The old item's epilogue
-        (P64_EPILOGUE*) follows this block."""
-        lines = self.save_lm_lines() + self.first_lines(pn, masked)
-        n1 = len(lines) // 2
-        self.phase_y(pn ^ 1, False, fill=lines[:n1])
-        self.phase_x(pn ^ 1, False, fill=lines[n1:])
+        -> LOLD / MOLD and the textbook softmax of tile g (buffer pn; masked: behind its mask) in the gaps of phase Y, the
+        old item's epilogue (epilogue_lines: O out through the wave's LDS staging area, O := 0) in the gaps of phase X."""
+        self.phase_y(pn ^ 1, False, fill=self.save_lm_lines() + self.first_lines(pn, masked))
+        # (the first two gaps of phase X stay free of O reads: the last P.V results are then readable by the VALU)
+        self.phase_x(pn ^ 1, False, fill=self.epilogue_lines(pn))
         return self.out
 
     def save_lm_block(self):
@@ -717,19 +808,23 @@ class Stream:
             self.e("s_add_u32 %[off], %[off], %[step]")
         return self.out
 
-    def epilogue_block(self, pn):
+    def epilogue_lines(self, pn):
         """O / l of both chains -> global memory as whole rows (reference prefill.cuh:600-612): 1/l (1 for a row without
         keys), pack, this wave's LDS staging area (32 rows of 272 bytes, one chain at a time), rows back as 16-byte
         pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped); then O := 0 for the next item.
         Runs BETWEEN two work items, possibly after the next item's first softmax: l comes from LOLD, and the only
         temporaries are registers that hold nothing of the next item -- the V fragment ring, the chain temporaries and the
         upper halves of buffer pn's 16-register blocks (packed P sits in the lower halves; buffer pn^1 holds raw scores).
+        A line list for fill_line() (its waits are "@wait n"): a block of its own (P64_EPILOGUE*) or the fill of the joint
+        block's phase X.
         %[wr] = stage + r*272 + 8h, %[rd] = stage + (lane/16)*272 + 16*(lane%16), %[ovoff] = (first row of the wave +
-        lane/16) * row bytes + 16*(lane%16), %[osb4] = 4 rows in bytes"""
+        lane/16) * row bytes + 16*(lane%16), %[ooff] = byte offset of the item's (batch, head) from the descriptor's base (the
+        O tensor's), %[osb4] = 4 rows in bytes"""
+        out, self.out = self.out, []
         X = lambda n: VFR(n % 4)                                            # pack groups: 4 x 4 registers
         R = lambda it: S_BASE(pn, it >> 2) + 16 * ((it >> 1) & 1) + 8 + 4 * (it & 1)  # row pieces: 8 x 4 registers
         inv = [TMP(0, 0), TMP(1, 0)]
-        self.pads()
+        ops = 0  # LDS operations issued so far
         for ch in range(2):
             t0, t1 = TMP(ch, 1), TMP(ch, 2)
             self.e(f"v_mov_b32 {vr(t0)}, {vr(LOLD(ch))}")
@@ -742,13 +837,15 @@ class Stream:
             t0, t1 = TMP(ch, 1), TMP(ch, 2)
             self.e(f"v_add_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
             self.e(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
+        for ch in range(2):  # (VCC: one chain's compare / select pair at a time)
+            t0, t1 = TMP(ch, 1), TMP(ch, 2)
             self.e(f"v_cmp_lt_f32 vcc, 0, {vr(t0)}")
             self.e("s_nop 0")
             self.e(f"v_cndmask_b32 {vr(inv[ch])}, 1.0, {vr(t1)}, vcc")
-        self.e(f"s_mov_b32 s{S_T0}, 0")
+        self.e(f"s_mov_b32 s{S_T0}, %[ooff]")  # (byte offset of the item's (batch, head) in the O tensor)
         for ch in range(2):
             if ch == 1:
-                self.e("s_waitcnt lgkmcnt(0)")
+                self.e(f"@wait {ops - 1}")  # chain 0's rows have left the staging area
             n = 0
             for d in range(4):
                 for g4 in range(4):
@@ -761,15 +858,34 @@ class Stream:
                     self.e(f"{self.cvt} {vr(x)}, {vr(x)}, {vr(x + 1)}")
                     self.e(f"{self.cvt} {vr(x + 1)}, {vr(x + 2)}, {vr(x + 3)}")
                     self.e(f"ds_write_b64 %[wr], {vr(x, 2)} offset:{16 * (4 * d + g4)}")
-            self.e("s_waitcnt lgkmcnt(0)")
+                    ops += 1
+            self.e(f"@wait {ops - 1}")
+            first_read = ops
             for it in range(8):
                 self.e(f"ds_read_b128 {vr(R(it), 4)}, %[rd] offset:{it * 4 * 272}")
+                ops += 1
             for it in range(8):
-                self.e(f"s_waitcnt lgkmcnt({7 - it})")
+                self.e(f"@wait {first_read + it}")
                 self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen")
                 self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[osb4]")
-        for i in range(128):
-            self.e(f"v_accvgpr_write_b32 {ar(i)}, 0")
+        # O := 0 for the next item: eight matrix instructions on zero operands (128 register writes would cost the wave 128 issue
+        # slots; a wave issues one instruction per 4-7 cycles whatever it is)
+        z = VFR(0)
+        for i in range(4):
+            self.e(f"v_mov_b32 {vr(z + i)}, 0")
+        self.e("s_nop 1")
+        for c in range(2):
+            for d in range(4):
+                self.e(f"{self.mf} {ar(O_BASE(c, d), 16)}, {vr(z, 4)}, {vr(z, 4)}, 0")
+        lines, self.out = self.out, out
+        return lines
+
+    def epilogue_block(self, pn):
+        self.lds_log = []
+        self._e_ops = 0
+        self.pads()
+        for ln in self.epilogue_lines(pn):
+            self.fill_line(ln)
         self.pads()
         return self.out
 
@@ -795,9 +911,10 @@ class Stream:
     def q_global_block(self):
         """Q fragments of a work item straight from global memory -> home registers (the rarely-run way back to an item's Q
         after the next item's has replaced it: P64_REDO* in the iteration that already carries the next item's first
-        scores).  %[qv] = r * row bytes + 16 h, %[q32] = 32 rows in bytes, %[srd]: descriptor of the wave's rows"""
+        scores).  %[qv] = r * row bytes + 16 h, %[q0] = byte offset of the wave's first row from the descriptor's base (the Q
+        tensor's), %[q32] = 32 rows in bytes, %[srd]: descriptor ending with the item's last row"""
         for c in range(2):
-            self.e(f"s_mov_b32 s{S_T0}, 0" if c == 0 else f"s_mov_b32 s{S_T0}, %[q32]")
+            self.e(f"s_mov_b32 s{S_T0}, %[q0]" if c == 0 else f"s_add_u32 s{S_T0}, %[q0], %[q32]")
             for ks in range(8):
                 self.e(f"buffer_load_dwordx4 {ar(Q_BASE(c, ks), 4)}, %[qv], %[srd], s{S_T0} offen offset:{ks * 32}")
         self.e("s_waitcnt vmcnt(0)")
@@ -841,7 +958,9 @@ ABLATIONS = [("dma",), ("sm",), ("lds",), ("dma", "sm", "lds"), ("dma", "lds"), 
 
 # ---- operand / clobber lists (C++ names of mfa_prefill64.hip) -------------------------------------------------------------
 S_TMP = [f"s{i}" for i in range(84, 86)]
-C_OP = '[c] "s"(c_log2)'
+C_OP = '[c] "v"(c_log2)'  # (a VGPR: scalar registers are the scarce ones in this kernel)
+if os.environ.get("P64_C_SGPR") == "1":  # (developer A/B)
+    C_OP = '[c] "s"(c_log2)'
 
 
 def all_regs(exclude=()):
@@ -850,8 +969,8 @@ def all_regs(exclude=()):
             [f"a{i}" for i in range(AB, AB + NA) if f"a{i}" not in ex])
 
 
-def clob(regs):
-    return ", ".join(f'"{r}"' for r in regs + S_TMP + ["vcc", "scc", "memory"])
+def clob(regs, extra=()):
+    return ", ".join(f'"{r}"' for r in regs + S_TMP + list(extra) + ["vcc", "scc", "memory"])
 
 
 def rng(kind, lo, n):
@@ -866,7 +985,7 @@ def pin(kind, lo, n, mode=""):
     return f'"{mode}{{{kind}[{lo}:{lo + n - 1}]}}"'
 
 
-def emit_block(fh, name, lines_of, outs, ins, exclude=()):
+def emit_block(fh, name, lines_of, outs, ins, exclude=(), sregs=()):
     n = 0
     for suffix, f16 in (("F16", True), ("BF16", False)):
         lines = lines_of(Stream(f16))
@@ -876,7 +995,7 @@ def emit_block(fh, name, lines_of, outs, ins, exclude=()):
         fh.write('    ""\n')
         n = sum(1 for ln in lines if not ln.startswith(';') and not ln.endswith(':'))
     fh.write(f"// {name}: {n} instructions\n")
-    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude)) + "\n\n")
+    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude), sregs) + "\n\n")
 
 
 def main():
@@ -889,8 +1008,11 @@ def main():
         path = sys.argv[sys.argv.index("--out") + 1]
     KS, VS = '[kslot] "s"(kslot)', '[vslot] "s"(vslot)'
     steady_outs = ['[j] "+s"(j)', '[koff] "+s"(k_off)', '[voff] "+s"(v_off)', '[status] "=&s"(status)']
-    steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[ksrd] "s"(k_srd)', '[vsrd] "s"(v_srd)', '[k16] "s"(k_step)',
-                  '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)', C_OP]
+    steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[kb0] "s"(kb0)', '[kb1] "s"(kb1)', '[vb0] "s"(vb0)', '[vb1] "s"(vb1)',
+                  '[knrec] "s"(k_nrec)', '[vnrec] "s"(v_nrec)', '[k16] "s"(k_step)', '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)',
+                  '[jsw] "s"(jsw)', '[koff2] "s"(k_off2)', '[knrec2] "s"(k_nrec2)', '[voff2] "s"(v_off2)', '[vnrec2] "s"(v_nrec2)',
+                  '[qoff] "s"(q_swap_off)', '[relax] "s"(vm_relax)', C_OP]
+    steady_sregs = [f"s{r}" for r in range(KSRD, KSRD + 4)] + [f"s{r}" for r in range(VSRD, VSRD + 4)]
     with open(path, "w") as fh:
         fh.write("// GENERATED by tools/gen_p64_stream.py -- do not edit.  The instruction streams of prefill64_kernel as inline-asm\n")
         fh.write("// blocks (one text per element type) with their operand lists; register map in the generator's docstring.\n")
@@ -906,17 +1028,23 @@ def main():
         emit_block(fh, "P64_DMA_Q", lambda st: st.dma_q_block(), ['[off] "+s"(dma_off)'],
                    ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
         emit_block(fh, "P64_Q_LDS", lambda st: st.q_lds_block(), [], ['[qoff] "s"(q_lds_off)'])
-        emit_block(fh, "P64_Q_GLOBAL", lambda st: st.q_global_block(), [], ['[qv] "v"(q_voff)', '[q32] "s"(q_step32)', '[srd] "s"(dma_srd)'])
+        emit_block(fh, "P64_Q_GLOBAL", lambda st: st.q_global_block(), [], ['[qv] "v"(q_voff)', '[q0] "s"(q_off_w)', '[q32] "s"(q_step32)', '[srd] "s"(dma_srd)'])
         emit_block(fh, "P64_SAVE_LM", lambda st: st.save_lm_block(), [], [])
-        emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
+        emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins, sregs=steady_sregs)
         MS = ['[skm1] "s"(skm1)', '[j64] "s"(j64)']
         for pn in range(2):
             emit_block(fh, f"P64_XN{pn}", lambda st, pn=pn: st.xn_block(pn), [], [KS])
+            emit_block(fh, f"P64_XNA{pn}", lambda st, pn=pn: st.xna_block(pn, False), [], [KS, C_OP])
+            emit_block(fh, f"P64_XNA{pn}_M", lambda st, pn=pn: st.xna_block(pn, True), [], [KS, C_OP] + MS)
+            emit_block(fh, f"P64_XFB{pn}", lambda st, pn=pn: st.xfb_block(pn), [], [KS, C_OP])
+            emit_block(fh, f"P64_FIRSTB{pn}", lambda st, pn=pn: st.firstb_block(pn), [], [C_OP])
             emit_block(fh, f"P64_XF{pn}", lambda st, pn=pn: st.xf_block(pn, False), [], [KS, C_OP])
             emit_block(fh, f"P64_XF{pn}_M", lambda st, pn=pn: st.xf_block(pn, True), [], [KS, C_OP] + MS)
             emit_block(fh, f"P64_FIRST{pn}", lambda st, pn=pn: st.first_block(pn), [], [C_OP])
-            emit_block(fh, f"P64_BNDB{pn}", lambda st, pn=pn: st.bndb_block(pn, False), [], [KS, VS, C_OP])
-            emit_block(fh, f"P64_BNDB{pn}_M", lambda st, pn=pn: st.bndb_block(pn, True), [], [KS, VS, C_OP] + MS)
+            EP = ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[ooff] "s"(o_off)', '[osb4] "s"(o_step)']
+            LM = rng("v", LOLD(0), 2) + rng("v", MOLD(0), 2)
+            emit_block(fh, f"P64_BNDB{pn}", lambda st, pn=pn: st.bndb_block(pn, False), [], [KS, VS, C_OP] + EP, exclude=LM)
+            emit_block(fh, f"P64_BNDB{pn}_M", lambda st, pn=pn: st.bndb_block(pn, True), [], [KS, VS, C_OP] + MS + EP, exclude=LM)
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
             emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [], [VS, C_OP])
@@ -927,7 +1055,7 @@ def main():
             for ch in range(2):
                 emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [], MS + [KS, C_OP])
             emit_block(fh, f"P64_EPILOGUE{pn}", lambda st, pn=pn: st.epilogue_block(pn), [],
-                       ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[osb4] "s"(o_step)'],
+                       ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[ooff] "s"(o_off)', '[osb4] "s"(o_step)'],
                        exclude=rng("v", LOLD(0), 2) + rng("v", MOLD(0), 2))
         emit_block(fh, "P64_CHECK", lambda st: st.check_block(), ['[status] "=&s"(status)'], [])
         for nm, isv in (("P64_DMA_K", False), ("P64_DMA_V", True)):
@@ -948,7 +1076,7 @@ def main():
                 def ablated(st, tags=tags):
                     st.ablate = set(tags)
                     return st.steady()
-                emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins)
+                emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins, sregs=steady_sregs)
         print("wrote", os.path.relpath(dev, root))
 
 

@@ -57,7 +57,8 @@ def run_wave(items, wave, sq, sk, has_hi, hi, no_loop=False):
             v_tile = tile_of(g + 1) if v_cur else cn["nt"] - 1 - (g + 1 - (gl + 1))
             if g == gl and warm_next and cn["nt_w"] > 0 and not q_is_next:
                 ev.append(("qswap", idx + 1)); q_is_next = True
-            if sm == "normal" and has_x and not no_loop:
+            first_a_done = g == ga and g > G0  # (the wave's first tile: its scores, mask and row maximum came in iteration g - 1)
+            if (sm == "normal" or (sm == "first" and first_a_done)) and has_x and not no_loop:
                 jend = gl - 1 if g <= gl - 2 else g + 1
                 for j in range(g, jend):
                     ev.append(("barrier",))
@@ -66,7 +67,8 @@ def run_wave(items, wave, sq, sk, has_hi, hi, no_loop=False):
                     else: ev.append(("dmaK0", j + 2))
                     if v_any: ev.append(("dmaV", idx if v_cur else idx + 1, vt, j + 1))
                     else: ev.append(("dmaV0", j + 1))
-                    ev.append(("Y", idx, j - 1)); ev.append(("SM", idx, j)); ev.append(("X", idx if j + 1 <= gl else idx + 1, j + 1))
+                    if j - 1 >= ga: ev.append(("Y", idx, j - 1))  # (else: the empty tile before the wave's first)
+                    ev.append(("SM", idx, j)); ev.append(("X", idx if j + 1 <= gl else idx + 1, j + 1))
                 g = jend
                 continue
             ev.append(("barrier",))
