@@ -38,28 +38,26 @@
 #define MFA_DEV_STAMP_FLUSH(lse, tid, nt)
 #endif
 
-// ---- prefill64_kernel (mfa_prefill64.hip): stamps of the workgroup's first two work items by its last wave (64 x u64 per
-// workgroup at Sched::dev_ptr, MFA_P64_DEBUG bit 1; bits 8-9: which wave stamps) and timing-only variants of the loop block (MFA_P64_DEBUG >> 2)
+// ---- prefill64_kernel (mfa_prefill64.hip): stamps of the workgroup's first two work items by its last wave (16 x u64 per
+// workgroup at Sched::dev_ptr, MFA_P64_DEBUG bit 1) and timing-only variants of the loop block (MFA_P64_DEBUG >> 2)
 #ifdef MFA_DEV_P64
 #define MFA_DEV_P64_ENTRY const unsigned long long mfa_dev_t_entry = __builtin_amdgcn_s_memtime()
 #define MFA_DEV_P64_STAMPS(sc, wave, lane, NW)                                                                         \
     unsigned long long* mfa_dev_stamps =                                                                               \
-        ((sc).dev_variant & 2) && (sc).dev_ptr && (wave) == (((sc).dev_variant >> 8) & 3) && (lane) == 0 ? (sc).dev_ptr + (size_t)blockIdx.x * 64 : nullptr; \
+        ((sc).dev_variant & 2) && (sc).dev_ptr && (wave) == (NW) - 1 && (lane) == 0 ? (sc).dev_ptr + (size_t)blockIdx.x * 16 : nullptr; \
     int mfa_dev_items = 0
 #define MFA_DEV_P64_FIRST do { if (mfa_dev_stamps) mfa_dev_stamps[0] = mfa_dev_t_entry; } while (0)
 #define MFA_DEV_P64_STAMP(i) do { if (mfa_dev_stamps) mfa_dev_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
-/* barrier passed in iteration `it` of the item (0 = its first): stamps 16 + it, for the stamped item only */
-#define MFA_DEV_P64_BAR(it) do { if (mfa_dev_stamps && mfa_dev_items == 1 && (unsigned)(it) < 48u) mfa_dev_stamps[16 + (it)] = __builtin_amdgcn_s_memtime(); } while (0)
 #define MFA_DEV_P64_ITEM_DONE(nt, nt_w)                                                                                \
     do {                                                                                                               \
         if (mfa_dev_stamps) mfa_dev_stamps[7] = ((unsigned long long)(nt) << 32) | (unsigned)(nt_w);                   \
         if (++mfa_dev_items == 2) mfa_dev_stamps = nullptr; /* the second item: the steady-state item boundary */       \
         else if (mfa_dev_stamps) mfa_dev_stamps[0] = __builtin_amdgcn_s_memtime();                                     \
     } while (0)
-#define MFA_DEV_P64_VARIANT(sc) (__builtin_expect((((sc).dev_variant >> 2) & 63) != 0, 0))
+#define MFA_DEV_P64_VARIANT(sc) (__builtin_expect(((sc).dev_variant >> 2) != 0, 0))
 #define MFA_DEV_P64_RUN_VARIANT(sc)                                                                                    \
     do {                                                                                                               \
-        switch (((sc).dev_variant >> 2) & 63) {                                                                               \
+        switch ((sc).dev_variant >> 2) {                                                                               \
         case 1: P64_RUN(P64_STEADY_ABL1); break;                                                                       \
         case 2: P64_RUN(P64_STEADY_ABL2); break;                                                                       \
         case 3: P64_RUN(P64_STEADY_ABL3); break;                                                                       \
@@ -75,7 +73,6 @@
 #define MFA_DEV_P64_STAMPS(sc, wave, lane, NW)
 #define MFA_DEV_P64_FIRST
 #define MFA_DEV_P64_STAMP(i)
-#define MFA_DEV_P64_BAR(it)
 #define MFA_DEV_P64_ITEM_DONE(nt, nt_w)
 #define MFA_DEV_P64_VARIANT(sc) false
 #define MFA_DEV_P64_RUN_VARIANT(sc)

@@ -80,8 +80,8 @@ def test_compiler_code_stays_out_of_the_streams_registers(p64_asm):
             if any(owned(r) for r in regs(code)):
                 touching.append(code)
         # the only owned registers compiler code may touch are the operands PINNED to their homes: the inputs of P64_SETUP
-        # (LDS read addresses, DMA lane offsets, 4h) and the outputs of P64_FINAL (l, m of the item whose epilogue ran)
+        # (LDS read addresses, DMA lane offsets, 4h) and the outputs of P64_FINAL (l, m)
         pinned = {("v", gen.VB + r) for r in ([gen.KRD(k) for k in range(8)] + [gen.VRD(d) for d in range(4)] + [gen.V_KGO, gen.V_VGO, gen.H4] +
-                                              list(gen.QGO) + [gen.LOLD(0), gen.LOLD(1), gen.MOLD(0), gen.MOLD(1)])}
+                                              list(gen.QGO) + [gen.L(0), gen.L(1), gen.M(0), gen.M(1)])}
         stray = sorted({r for c in touching for r in regs(c) if owned(r)} - pinned)
         assert not stray and 0 < len(touching) <= 64, (name, stray, touching[:10])

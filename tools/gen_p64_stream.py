@@ -87,7 +87,7 @@ NW = 4
 NI = 16 // NW
 LIMIT = 0x44800000  # 1024.0f
 NEG_INF = 0xFF800000
-NV, NA = 184, 208    # reserved VGPRs / AGPRs
+NV, NA = 180, 208    # reserved VGPRs / AGPRs
 VB, AB = 72, 48      # first reserved VGPR / AGPR
 
 
@@ -138,14 +138,6 @@ def TMP(c, i):  # three temporaries per chain
     return 174 + 3 * c + i
 
 
-def LOLD(c):  # l / m of the work item whose epilogue is still to run (P64_SAVE_LM: the next item's first tile overwrites l, m)
-    return 180 + c
-
-
-def MOLD(c):
-    return 182 + c
-
-
 def O_BASE(c, d):
     return (4 * c + d) * 16
 
@@ -159,7 +151,6 @@ def KFR(k):
 
 
 S_T0 = 84  # scalar temporary
-KSRD, VSRD = 88, 92  # P64_STEADY: the K / V buffer descriptors live in s[88:91] / s[92:95] (set from operands at entry)
 
 
 def vr(lo, n=1):
@@ -178,7 +169,6 @@ class Stream:
         self.mf = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.lds_log = []
-        self._e_ops = 0
         self.ablate = set()  # developer timing builds: "dma", "sm", "lds" leave that part of the steady loop out
 
     def e(self, s):
@@ -255,18 +245,6 @@ class Stream:
         if pad:
             self.e("s_nop 3")
 
-    def fill_line(self, ln):
-        """one line of a phase's `fill` list.  LDS operations among them are logged like the phase's own fragment reads, and
-        "@wait n" (all of the fill's LDS operations up to its n-th have completed) becomes a counted wait over both."""
-        if ln.startswith("@wait "):
-            last = max(i for i, t in enumerate(self.lds_log) if t == ("E", int(ln.split()[1])))
-            self.e(f"s_waitcnt lgkmcnt({len(self.lds_log) - 1 - last})")
-            return
-        if ln.startswith("ds_"):
-            self.lds_log.append(("E", self._e_ops))
-            self._e_ops += 1
-        self.e(ln)
-
     def filler(self):
         for tag in self.ablate:
             if tag.startswith("fill"):
@@ -306,32 +284,6 @@ class Stream:
         if "bar" not in self.ablate:
             self.e("s_waitcnt vmcnt(0)")
             self.e("s_barrier")
-        self.e(f"6{i}:")
-        # The work item's last two iterations, jsw and jsw + 1, request the NEXT item's first tiles: K from iteration jsw on
-        # (K(j+2)), V from jsw + 1 on (V(j+1)) -- new offsets and descriptor lengths, same base -- and iteration jsw + 1 runs
-        # phase X on the next item's Q rows: LDS Q buffer (%[qoff] = its offset from the K ring's slot 0; 0: no such rows) ->
-        # Q registers, idle during phase Y.  The extra LDS reads are drained here: the counted waits below stay valid.
-        self.e("s_cmp_lt_i32 %[j], %[jsw]")
-        self.e(f"s_cbranch_scc1 4{i}f")
-        self.e("s_cmp_lg_u32 %[j], %[jsw]")
-        self.e(f"s_cbranch_scc1 5{i}f")
-        self.e("s_mov_b32 %[koff], %[koff2]")
-        self.e(f"s_mov_b32 s{KSRD + 2}, %[knrec2]")
-        self.e(f"s_branch 4{i}f")
-        self.e(f"5{i}:")
-        self.e("s_mov_b32 %[voff], %[voff2]")
-        self.e(f"s_mov_b32 s{VSRD + 2}, %[vnrec2]")
-        self.e("s_cmp_eq_u32 %[qoff], 0")
-        self.e(f"s_cbranch_scc1 4{i}f")
-        for ks0 in (0, 6):
-            n = min(6, 8 - ks0)
-            for k in range(n):
-                self.e(f"v_add_u32 {vr(TMP(0, 0) + k)}, %[qoff], {vr(KRD(ks0 + k))}")
-            for c in range(2):
-                for k in range(n):
-                    self.e(f"ds_read_b128 {ar(Q_BASE(c, ks0 + k), 4)}, {vr(TMP(0, 0) + k)} offset:{c * 32 * 256}")
-        self.e("s_waitcnt lgkmcnt(0)")
-        self.e(f"4{i}:")
         # ---- phase Y: O^T += V^T.P^T of tile j-1 (slot t: chain t & 1, V fragment t >> 1 = 4*s16 + d).  The wait for a
         # fragment sits behind the MFMA of the slot before its first use (that slot's fillers separate it from the
         # consumer).  Fragment f + PF is read into the ring entry fragment f - 1 has left: its low half behind the first
@@ -349,9 +301,9 @@ class Stream:
             if dma:
                 pc = f // 2
                 if pc < NI:
-                    self.e(f"s_add_u32 m0, %[dst0], {((i + 2) % 3) * TILE + (NI - 1 - pc) * NW * 1024}")
+                    self.e(f"s_add_u32 m0, %[dst0], {((i + 2) % 3) * TILE + pc * NW * 1024}")
                 else:
-                    self.e(f"s_add_u32 m0, %[dst0], {V_RING + ((i + 1) % 3) * TILE + (2 * NI - 1 - pc) * NW * 1024}")
+                    self.e(f"s_add_u32 m0, %[dst0], {V_RING + ((i + 1) % 3) * TILE + (pc - NI) * NW * 1024}")
             if t == 0 and "sm" not in self.ablate:  # the sums of tile j-1 (accepted at the end of the last iteration)
                 for c2 in range(2):
                     self.e(f"v_add_f32 {vr(L(c2))}, {vr(L(c2))}, {vr(LT(c2))}")
@@ -362,11 +314,11 @@ class Stream:
                 self.k_read(f + PF - 16, 1, ks_)
             if dma:
                 if pc < NI:
-                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, s[{KSRD}:{KSRD + 3}], %[koff] offen lds")
-                    self.e("s_sub_u32 %[koff], %[koff], %[k16]")
+                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, %[ksrd], %[koff] offen lds")
+                    self.e("s_add_u32 %[koff], %[koff], %[k16]")
                 else:
-                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, s[{VSRD}:{VSRD + 3}], %[voff] offen lds")
-                    self.e("s_sub_u32 %[voff], %[voff], %[v16]")
+                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, %[vsrd], %[voff] offen lds")
+                    self.e("s_add_u32 %[voff], %[voff], %[v16]")
         # ---- phase X: S^T = K.Q^T of tile j+1 into the buffer P^1 (slot t: chain t & 1, K fragment t >> 1 = 8*kb + ks)
         for t in range(32):
             ch, f = t & 1, t >> 1
@@ -400,11 +352,6 @@ class Stream:
         self.e("s_mov_b32 %[status], 0")
         self.e("s_cmp_ge_i32 %[j], %[jend]")
         self.e("s_cbranch_scc1 9f")
-        for base, lo, hi, nrec in ((KSRD, "kb0", "kb1", "knrec"), (VSRD, "vb0", "vb1", "vnrec")):
-            self.e(f"s_mov_b32 s{base}, %[{lo}]")
-            self.e(f"s_mov_b32 s{base + 1}, %[{hi}]")
-            self.e(f"s_mov_b32 s{base + 2}, %[{nrec}]")
-            self.e(f"s_mov_b32 s{base + 3}, 0x20000")
         self.pads()
         for i in range(1, 6):
             self.e(f"s_cmp_eq_u32 %[entry], {i}")
@@ -417,19 +364,7 @@ class Stream:
             for c2 in range(2):
                 self.e(f"v_mov_b32 {vr(LT(c2))}, 0")
             self.wait_frag("V", 0, 0, pad=True)
-            # %[relax] = 16 / 32: the wave's 16 / 32 youngest memory operations (the old item's O stores, the next item's Q
-            # requests, issued after the last tile requests) need not have completed at this iteration's barrier
-            self.e("s_cmp_lt_u32 %[relax], 16")
-            self.e(f"s_cbranch_scc1 1{i}f")
-            self.e("s_cmp_lt_u32 %[relax], 32")
-            self.e(f"s_cbranch_scc1 3{i}f")
-            self.e("s_waitcnt vmcnt(32)")
-            self.e("s_barrier")
-            self.e(f"s_branch 6{i}f")
-            self.e(f"3{i}:")
-            self.e("s_waitcnt vmcnt(16)")
-            self.e("s_barrier")
-            self.e(f"s_branch 6{i}f")
+            self.e(f"s_branch 1{i}f")
         for i in range(6):
             self.iteration(i)
         self.e("s_branch 10b")
@@ -452,7 +387,6 @@ class Stream:
         fill = list(fill or [])
         share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
         self.lds_log = []
-        self._e_ops = 0
         self.pads()
         if slot is None:
             for ks in range(8):
@@ -471,8 +405,7 @@ class Stream:
                 self.wait_frag("K", 0, f + 1, pad=not sm and len(share[t]) < 3)
             if sm:
                 self.sm_step(PN ^ 1, 32 + t)
-            for ln in share[t]:
-                self.fill_line(ln)
+            self.out += share[t]
             if ch == 0 and f + PF <= 15:
                 self.k_read(f + PF, 0, slot)
         if sm:
@@ -483,11 +416,8 @@ class Stream:
         self.pads()
         return self.out
 
-    def phase_y(self, PP, sm, fill=None):
-        fill = list(fill or [])
-        share = [fill[len(fill) * t // 32:len(fill) * (t + 1) // 32] for t in range(32)]
+    def phase_y(self, PP, sm):
         self.lds_log = []
-        self._e_ops = 0
         self.pads()
         for d in range(4):
             self.e(f"v_add_u32 {vr(VRD(d))}, %[vslot], {vr(VRD(d))}")
@@ -498,11 +428,9 @@ class Stream:
             ch, f = t & 1, t >> 1
             self.mfma_y(PP, t)
             if ch == 1 and f < 15:
-                self.wait_frag("V", 0, f + 1, pad=not sm and len(share[t]) < 3)
+                self.wait_frag("V", 0, f + 1, pad=not sm)
             if sm:
                 self.sm_step(PP ^ 1, t)
-            for ln in share[t]:
-                self.fill_line(ln)
             if f + PF <= 15:
                 self.v_read_half(f + PF, ch)
         for d in range(4):
@@ -638,9 +566,6 @@ class Stream:
         self.e("s_nop 1")
         self.e(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")  # max of the raw scores over the row's 64 keys
         if first:
-            # (walking the tiles downwards, a row's first tile may hold no key it sees -- a causal offset that is not a
-            # multiple of 64: keep m finite; the row's next tile then fails the sum test and takes the textbook update)
-            self.e(f"v_max_f32 {vr(t0)}, 0xf149f2ca, {vr(t0)}")  # -1e30
             self.e(f"v_mov_b32 {vr(M(ch))}, {vr(t0)}")
         else:
             self.e(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(M(ch))}")  # m_new (a fully masked tile leaves m)
@@ -672,33 +597,10 @@ class Stream:
         lines, self.out = self.out, out
         return lines
 
-    def mask_lines(self, P, ch):
-        out, self.out = self.out, []
-        self.mask_chain(P, ch)
-        lines, self.out = self.out, out
-        return lines
-
-    def first_lines(self, P, masked=False, part="AB"):
-        """the first tile's textbook softmax (behind its mask, if any), the two chains' instructions alternating
-        (independent dependency chains).  part "A": mask, row maximum, m and -m*c only; "B": the rest (exponentials, sums,
-        packing, l) -- a wave that joins an item late does A right behind the tile's scores, in an iteration it otherwise idles
-        in, and B in the shadow of its second tile's scores."""
+    def first_lines(self, P):
+        """the first tile's textbook softmax, the two chains' instructions alternating (independent dependency chains)"""
         a, b = self.exact_softmax(P, 0, True), self.exact_softmax(P, 1, True)
-        assert len(a) == len(b)
-        cut = 1 + max(i for i, ln in enumerate(a) if ln.startswith("v_sub_f32 " + vr(MC(0)) + ","))
-        assert b[cut - 1].startswith("v_sub_f32 " + vr(MC(1)) + ",")
-        lo, hi = (0 if "A" in part else cut), (len(a) if "B" in part else cut)
-        # (the mask's compare / select pairs go through VCC: never interleaved with another chain's)
-        mask = self.mask_lines(P, 0) + self.mask_lines(P, 1) if masked and "A" in part else []
-        return mask + [x for pair in zip(a[lo:hi], b[lo:hi]) for x in pair]
-
-    def save_lm_lines(self):
-        """l, m of the item that has just seen its last tile -> LOLD / MOLD (its epilogue reads them there), l := 0 for the
-        next item's first tile"""
-        lines = []
-        for c in range(2):
-            lines += [f"v_mov_b32 {vr(LOLD(c))}, {vr(L(c))}", f"v_mov_b32 {vr(MOLD(c))}, {vr(M(c))}", f"v_mov_b32 {vr(L(c))}, 0"]
-        return lines
+        return [x for pair in zip(a, b) for x in pair]
 
     def mask_block(self, P):
         self.pads()
@@ -713,57 +615,9 @@ class Stream:
         self.e("s_nop 4")
         return self.out
 
-    def xn_block(self, pn):
-        """phase X alone: scores of the K tile in slot %[kslot] into buffer pn (a work item's first tile)"""
-        return self.phase_x(pn, False)
-
-    def xna_block(self, pn, masked):
-        """phase X alone (scores of the K tile in slot %[kslot] into buffer pn: a wave's first tile), then that tile's mask
-        (masked) and the first part of its textbook softmax (row maximum, m, -m*c) right behind"""
-        self.phase_x(pn, False)
-        self.out += self.first_lines(pn, masked, "A")
-        # P of the tile "before" the wave's first := 0 (the packed halves of buffer pn^1): the wave's next iteration can then be
-        # an ordinary one of the loop block -- P.V of that empty tile adds nothing, the softmax of the first tile runs with the
-        # m just set (its sums cannot fail the test) -- instead of a block of its own that the other waves wait for
-        for ch in range(2):
-            for kb in range(2):
-                for i in range(8):
-                    self.e(f"v_mov_b32 {vr(S_BASE(pn ^ 1, ch) + 16 * kb + i)}, 0")
-        self.e("s_nop 4")
-        return self.out
-
-    def xfb_block(self, pn):
-        """phase X of a wave's second tile (slot %[kslot]) into buffer pn with the second part of its first tile's textbook
-        softmax (buffer pn^1, after P64_XNA*) in the gaps"""
-        return self.phase_x(pn, False, fill=self.first_lines(pn ^ 1, False, "B"))
-
-    def firstb_block(self, pn):
-        self.pads()
-        self.out += self.first_lines(pn, False, "B")
-        self.e("s_nop 4")
-        return self.out
-
-    def xf_block(self, pn, masked):
-        """phase X of a wave's second tile (slot %[kslot]) into buffer pn with the textbook softmax of its first tile
-        (buffer pn^1; masked: behind that tile's mask, %[skm1], %[j64]) in the gaps"""
-        return self.phase_x(pn, False, fill=self.first_lines(pn ^ 1, masked))
-
-    def bndb_block(self, pn, masked):
-        """The iteration that joins two work items, for a wave that takes part in both without a gap: tile g (parity pn) is
-        the NEW item's first tile.  Phase Y: P.V of the OLD item's last tile (P in buffer pn^1, V tile in slot %[vslot]);
-        phase X: scores of the new item's second tile (slot %[kslot]) into buffer pn^1; in their gaps l, m of the old item
-        -> LOLD / MOLD and the textbook softmax of tile g (buffer pn; masked: behind its mask) in the gaps of phase Y, the
-        old item's epilogue (epilogue_lines: O out through the wave's LDS staging area, O := 0) in the gaps of phase X."""
-        self.phase_y(pn ^ 1, False, fill=self.save_lm_lines() + self.first_lines(pn, masked))
-        # (the first two gaps of phase X stay free of O reads: the last P.V results are then readable by the VALU)
-        self.phase_x(pn ^ 1, False, fill=self.epilogue_lines(pn))
-        return self.out
-
-    def save_lm_block(self):
-        self.pads()
-        self.out += self.save_lm_lines()
-        self.e("s_nop 4")
-        return self.out
+    def x_first_block(self):
+        """phase X of tile 1 (slot %[kslot], buffer 1) with the textbook softmax of tile 0 (buffer 0) in its gaps"""
+        return self.phase_x(1, False, fill=self.first_lines(0))
 
     def check_block(self):
         """status bit c = chain c failed the test of its tile sum; passing chains: l += lt"""
@@ -808,49 +662,39 @@ class Stream:
             self.e("s_add_u32 %[off], %[off], %[step]")
         return self.out
 
-    def epilogue_lines(self, pn):
+    def epilogue_block(self):
         """O / l of both chains -> global memory as whole rows (reference prefill.cuh:600-612): 1/l (1 for a row without
         keys), pack, this wave's LDS staging area (32 rows of 272 bytes, one chain at a time), rows back as 16-byte
-        pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped); then O := 0 for the next item.
-        Runs BETWEEN two work items, possibly after the next item's first softmax: l comes from LOLD, and the only
-        temporaries are registers that hold nothing of the next item -- the V fragment ring, the chain temporaries and the
-        upper halves of buffer pn's 16-register blocks (packed P sits in the lower halves; buffer pn^1 holds raw scores).
-        A line list for fill_line() (its waits are "@wait n"): a block of its own (P64_EPILOGUE*) or the fill of the joint
-        block's phase X.
+        pieces, buffer stores (rows >= seqlen_q fall outside the descriptor and are dropped).
         %[wr] = stage + r*272 + 8h, %[rd] = stage + (lane/16)*272 + 16*(lane%16), %[ovoff] = (first row of the wave +
-        lane/16) * row bytes + 16*(lane%16), %[ooff] = byte offset of the item's (batch, head) from the descriptor's base (the
-        O tensor's), %[osb4] = 4 rows in bytes"""
-        out, self.out = self.out, []
-        X = lambda n: VFR(n % 4)                                            # pack groups: 4 x 4 registers
-        R = lambda it: S_BASE(pn, it >> 2) + 16 * ((it >> 1) & 1) + 8 + 4 * (it & 1)  # row pieces: 8 x 4 registers
-        inv = [TMP(0, 0), TMP(1, 0)]
-        ops = 0  # LDS operations issued so far
+        lane/16) * row bytes + 16*(lane%16), %[osb4] = 4 rows in bytes"""
+        T = lambda i: S_BASE(0, 0) + i  # temporaries: the S buffers are free now
+        inv = [T(0), T(1)]
+        self.pads()
         for ch in range(2):
-            t0, t1 = TMP(ch, 1), TMP(ch, 2)
-            self.e(f"v_mov_b32 {vr(t0)}, {vr(LOLD(ch))}")
-            self.e(f"v_mov_b32 {vr(t1)}, {vr(LOLD(ch))}")
+            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
+            self.e(f"v_mov_b32 {vr(t0)}, {vr(L(ch))}")
+            self.e(f"v_mov_b32 {vr(t1)}, {vr(L(ch))}")
         self.e("s_nop 1")
         for ch in range(2):
-            self.e(f"v_permlane32_swap_b32 {vr(TMP(ch, 1))}, {vr(TMP(ch, 2))}")
+            self.e(f"v_permlane32_swap_b32 {vr(T(2 + 2 * ch))}, {vr(T(3 + 2 * ch))}")
         self.e("s_nop 1")
         for ch in range(2):
-            t0, t1 = TMP(ch, 1), TMP(ch, 2)
+            t0, t1 = T(2 + 2 * ch), T(3 + 2 * ch)
             self.e(f"v_add_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}")
             self.e(f"v_rcp_f32 {vr(t1)}, {vr(t0)}")
-        for ch in range(2):  # (VCC: one chain's compare / select pair at a time)
-            t0, t1 = TMP(ch, 1), TMP(ch, 2)
             self.e(f"v_cmp_lt_f32 vcc, 0, {vr(t0)}")
             self.e("s_nop 0")
             self.e(f"v_cndmask_b32 {vr(inv[ch])}, 1.0, {vr(t1)}, vcc")
-        self.e(f"s_mov_b32 s{S_T0}, %[ooff]")  # (byte offset of the item's (batch, head) in the O tensor)
+        self.e(f"s_mov_b32 s{S_T0}, 0")
         for ch in range(2):
             if ch == 1:
-                self.e(f"@wait {ops - 1}")  # chain 0's rows have left the staging area
+                self.e("s_waitcnt lgkmcnt(0)")
             n = 0
             for d in range(4):
                 for g4 in range(4):
-                    x = X(n)
-                    n += 1  # (a group's registers are free again once its ds_write has issued: LDS reads its operands at issue)
+                    x = T(8 + 4 * (n % 8))
+                    n += 1
                     for i in range(4):
                         self.e(f"v_accvgpr_read_b32 {vr(x + i)}, {ar(O_BASE(ch, d) + 4 * g4 + i)}")
                     for i in range(4):
@@ -858,72 +702,30 @@ class Stream:
                     self.e(f"{self.cvt} {vr(x)}, {vr(x)}, {vr(x + 1)}")
                     self.e(f"{self.cvt} {vr(x + 1)}, {vr(x + 2)}, {vr(x + 3)}")
                     self.e(f"ds_write_b64 %[wr], {vr(x, 2)} offset:{16 * (4 * d + g4)}")
-                    ops += 1
-            self.e(f"@wait {ops - 1}")
-            first_read = ops
+            self.e("s_waitcnt lgkmcnt(0)")
+            R = lambda it: T(48 + 4 * it)
             for it in range(8):
                 self.e(f"ds_read_b128 {vr(R(it), 4)}, %[rd] offset:{it * 4 * 272}")
-                ops += 1
             for it in range(8):
-                self.e(f"@wait {first_read + it}")
+                self.e(f"s_waitcnt lgkmcnt({7 - it})")
                 self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen")
                 self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[osb4]")
-        # O := 0 for the next item: eight matrix instructions on zero operands (128 register writes would cost the wave 128 issue
-        # slots; a wave issues one instruction per 4-7 cycles whatever it is)
-        z = VFR(0)
-        for i in range(4):
-            self.e(f"v_mov_b32 {vr(z + i)}, 0")
-        self.e("s_nop 1")
-        for c in range(2):
-            for d in range(4):
-                self.e(f"{self.mf} {ar(O_BASE(c, d), 16)}, {vr(z, 4)}, {vr(z, 4)}, 0")
-        lines, self.out = self.out, out
-        return lines
-
-    def epilogue_block(self, pn):
-        self.lds_log = []
-        self._e_ops = 0
-        self.pads()
-        for ln in self.epilogue_lines(pn):
-            self.fill_line(ln)
-        self.pads()
         return self.out
 
     def init_lines(self):
         lines = [f"v_accvgpr_write_b32 {ar(i)}, 0" for i in range(128)]
-        lines += [f"v_mov_b32 {vr(r)}, 0" for r in (L(0), L(1), LT(0), LT(1), M(0), M(1), MC(0), MC(1), LOLD(0), LOLD(1), MOLD(0), MOLD(1))]
+        lines += [f"v_mov_b32 {vr(r)}, 0" for r in (L(0), L(1), LT(0), LT(1), M(0), M(1), MC(0), MC(1))]
         return lines
-
-    def init_block(self):
-        """once per workgroup: O, l, m := 0"""
-        self.pads()
-        self.out += self.init_lines()
-        self.pads()
-        return self.out
-
-    def qhi_block(self):
-        """a work item's mask bounds (row + hi of this lane's row in chain 0 / 1) -> home registers"""
-        for c in range(2):
-            self.e(f"v_mov_b32 {vr(QHI(c))}, %[qhi{c}]")
-        self.e("s_nop 1")
-        return self.out
-
-    def q_global_block(self):
-        """Q fragments of a work item straight from global memory -> home registers (the rarely-run way back to an item's Q
-        after the next item's has replaced it: P64_REDO* in the iteration that already carries the next item's first
-        scores).  %[qv] = r * row bytes + 16 h, %[q0] = byte offset of the wave's first row from the descriptor's base (the Q
-        tensor's), %[q32] = 32 rows in bytes, %[srd]: descriptor ending with the item's last row"""
-        for c in range(2):
-            self.e(f"s_mov_b32 s{S_T0}, %[q0]" if c == 0 else f"s_add_u32 s{S_T0}, %[q0], %[q32]")
-            for ks in range(8):
-                self.e(f"buffer_load_dwordx4 {ar(Q_BASE(c, ks), 4)}, %[qv], %[srd], s{S_T0} offen offset:{ks * 32}")
-        self.e("s_waitcnt vmcnt(0)")
-        self.pads()
-        return self.out
 
     def setup_block(self):
         self.e("s_nop 0")
         return self.out
+
+    def x0_block(self):
+        """a new work item: phase X of its tile 0 (slot %[kslot]) into buffer 0; O, l := 0 and the item's mask bounds
+        (%[qhi0], %[qhi1]) -> home registers in its gaps.  Q is in its home registers (P64_Q_LDS)."""
+        lines = self.init_lines() + [f"v_mov_b32 {vr(QHI(c))}, %[qhi{c}]" for c in range(2)]
+        return self.phase_x(0, False, fill=lines)
 
     def dma_q_block(self):
         """the wave's 64 Q rows of a work item -> its LDS Q buffer, as a K-tile-shaped image (16 pieces of 4 rows; row i at
@@ -941,9 +743,8 @@ class Stream:
     def q_lds_block(self):
         """Q fragments (B operand of S^T = K.Q^T: row, columns 16*ks + 8h .. +7, as stored; the scale is applied to the
         fp32 scores) from the wave's LDS Q buffer -> home registers.  The image is K-tile-shaped, so the K read addresses
-        serve: %[qoff] = the buffer's offset from the K ring's slot 0.  Runs at the top of an item's last iteration (both S
-        buffers are live there): the address temporaries are the V fragment ring, idle between two iterations."""
-        T = lambda i: VFR(0) + i
+        serve: %[qoff] = the buffer's offset from the K ring's slot 0.  Run between two work items (S buffers free)."""
+        T = lambda i: S_BASE(0, 0) + i
         for ks in range(8):
             self.e(f"v_add_u32 {vr(T(ks))}, %[qoff], {vr(KRD(ks))}")
         for c in range(2):
@@ -958,9 +759,7 @@ ABLATIONS = [("dma",), ("sm",), ("lds",), ("dma", "sm", "lds"), ("dma", "lds"), 
 
 # ---- operand / clobber lists (C++ names of mfa_prefill64.hip) -------------------------------------------------------------
 S_TMP = [f"s{i}" for i in range(84, 86)]
-C_OP = '[c] "v"(c_log2)'  # (a VGPR: scalar registers are the scarce ones in this kernel)
-if os.environ.get("P64_C_SGPR") == "1":  # (developer A/B)
-    C_OP = '[c] "s"(c_log2)'
+C_OP = '[c] "s"(c_log2)'
 
 
 def all_regs(exclude=()):
@@ -969,8 +768,8 @@ def all_regs(exclude=()):
             [f"a{i}" for i in range(AB, AB + NA) if f"a{i}" not in ex])
 
 
-def clob(regs, extra=()):
-    return ", ".join(f'"{r}"' for r in regs + S_TMP + list(extra) + ["vcc", "scc", "memory"])
+def clob(regs):
+    return ", ".join(f'"{r}"' for r in regs + S_TMP + ["vcc", "scc", "memory"])
 
 
 def rng(kind, lo, n):
@@ -985,7 +784,7 @@ def pin(kind, lo, n, mode=""):
     return f'"{mode}{{{kind}[{lo}:{lo + n - 1}]}}"'
 
 
-def emit_block(fh, name, lines_of, outs, ins, exclude=(), sregs=()):
+def emit_block(fh, name, lines_of, outs, ins, exclude=()):
     n = 0
     for suffix, f16 in (("F16", True), ("BF16", False)):
         lines = lines_of(Stream(f16))
@@ -995,7 +794,7 @@ def emit_block(fh, name, lines_of, outs, ins, exclude=(), sregs=()):
         fh.write('    ""\n')
         n = sum(1 for ln in lines if not ln.startswith(';') and not ln.endswith(':'))
     fh.write(f"// {name}: {n} instructions\n")
-    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude), sregs) + "\n\n")
+    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude)) + "\n\n")
 
 
 def main():
@@ -1008,11 +807,8 @@ def main():
         path = sys.argv[sys.argv.index("--out") + 1]
     KS, VS = '[kslot] "s"(kslot)', '[vslot] "s"(vslot)'
     steady_outs = ['[j] "+s"(j)', '[koff] "+s"(k_off)', '[voff] "+s"(v_off)', '[status] "=&s"(status)']
-    steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[kb0] "s"(kb0)', '[kb1] "s"(kb1)', '[vb0] "s"(vb0)', '[vb1] "s"(vb1)',
-                  '[knrec] "s"(k_nrec)', '[vnrec] "s"(v_nrec)', '[k16] "s"(k_step)', '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)',
-                  '[jsw] "s"(jsw)', '[koff2] "s"(k_off2)', '[knrec2] "s"(k_nrec2)', '[voff2] "s"(v_off2)', '[vnrec2] "s"(v_nrec2)',
-                  '[qoff] "s"(q_swap_off)', '[relax] "s"(vm_relax)', C_OP]
-    steady_sregs = [f"s{r}" for r in range(KSRD, KSRD + 4)] + [f"s{r}" for r in range(VSRD, VSRD + 4)]
+    steady_ins = ['[jend] "s"(jend)', '[entry] "s"(entry)', '[ksrd] "s"(k_srd)', '[vsrd] "s"(v_srd)', '[k16] "s"(k_step)',
+                  '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)', C_OP]
     with open(path, "w") as fh:
         fh.write("// GENERATED by tools/gen_p64_stream.py -- do not edit.  The instruction streams of prefill64_kernel as inline-asm\n")
         fh.write("// blocks (one text per element type) with their operand lists; register map in the generator's docstring.\n")
@@ -1023,48 +819,35 @@ def main():
         fixed_regs = (rng("v", KRD(0), 8) + rng("v", VRD(0), 4) + rng("v", V_KGO, 2) + rng("v", QGO[0], 2) +
                       rng("v", QGO[2], 2) + rng("v", H4, 1))
         emit_block(fh, "P64_SETUP", lambda st: st.setup_block(), [], fixed_ins, exclude=fixed_regs)
-        emit_block(fh, "P64_INIT", lambda st: st.init_block(), [], [])
-        emit_block(fh, "P64_QHI", lambda st: st.qhi_block(), [], ['[qhi0] "v"(qhi0)', '[qhi1] "v"(qhi1)'])
         emit_block(fh, "P64_DMA_Q", lambda st: st.dma_q_block(), ['[off] "+s"(dma_off)'],
                    ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
         emit_block(fh, "P64_Q_LDS", lambda st: st.q_lds_block(), [], ['[qoff] "s"(q_lds_off)'])
-        emit_block(fh, "P64_Q_GLOBAL", lambda st: st.q_global_block(), [], ['[qv] "v"(q_voff)', '[q0] "s"(q_off_w)', '[q32] "s"(q_step32)', '[srd] "s"(dma_srd)'])
-        emit_block(fh, "P64_SAVE_LM", lambda st: st.save_lm_block(), [], [])
-        emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins, sregs=steady_sregs)
-        MS = ['[skm1] "s"(skm1)', '[j64] "s"(j64)']
+        emit_block(fh, "P64_X0", lambda st: st.x0_block(), [], [KS, '[qhi0] "v"(qhi0)', '[qhi1] "v"(qhi1)'])
+        emit_block(fh, "P64_FIRST0", lambda st: st.first_block(0), [], [C_OP])
+        emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [], [KS, C_OP])
+        emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
         for pn in range(2):
-            emit_block(fh, f"P64_XN{pn}", lambda st, pn=pn: st.xn_block(pn), [], [KS])
-            emit_block(fh, f"P64_XNA{pn}", lambda st, pn=pn: st.xna_block(pn, False), [], [KS, C_OP])
-            emit_block(fh, f"P64_XNA{pn}_M", lambda st, pn=pn: st.xna_block(pn, True), [], [KS, C_OP] + MS)
-            emit_block(fh, f"P64_XFB{pn}", lambda st, pn=pn: st.xfb_block(pn), [], [KS, C_OP])
-            emit_block(fh, f"P64_FIRSTB{pn}", lambda st, pn=pn: st.firstb_block(pn), [], [C_OP])
-            emit_block(fh, f"P64_XF{pn}", lambda st, pn=pn: st.xf_block(pn, False), [], [KS, C_OP])
-            emit_block(fh, f"P64_XF{pn}_M", lambda st, pn=pn: st.xf_block(pn, True), [], [KS, C_OP] + MS)
-            emit_block(fh, f"P64_FIRST{pn}", lambda st, pn=pn: st.first_block(pn), [], [C_OP])
-            EP = ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[ooff] "s"(o_off)', '[osb4] "s"(o_step)']
-            LM = rng("v", LOLD(0), 2) + rng("v", MOLD(0), 2)
-            emit_block(fh, f"P64_BNDB{pn}", lambda st, pn=pn: st.bndb_block(pn, False), [], [KS, VS, C_OP] + EP, exclude=LM)
-            emit_block(fh, f"P64_BNDB{pn}_M", lambda st, pn=pn: st.bndb_block(pn, True), [], [KS, VS, C_OP] + MS + EP, exclude=LM)
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])
             emit_block(fh, f"P64_Y{pn}_SM", lambda st, pn=pn: st.phase_y(pn, True), [], [VS, C_OP])
             emit_block(fh, f"P64_LAST{pn}", lambda st, pn=pn: st.last_block(pn, False), ['[status] "=&s"(status)'], [VS, C_OP])
             emit_block(fh, f"P64_LAST{pn}_M", lambda st, pn=pn: st.last_block(pn, True), ['[status] "=&s"(status)'],
-                       [VS, C_OP] + MS)
-            emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], MS)
+                       [VS, C_OP, '[skm1] "s"(skm1)', '[j64] "s"(j64)'])
+            emit_block(fh, f"P64_SM2_{pn}", lambda st, pn=pn: st.sm_second_half(pn), [], [C_OP])
+            emit_block(fh, f"P64_MASK{pn}", lambda st, pn=pn: st.mask_block(pn), [], ['[skm1] "s"(skm1)', '[j64] "s"(j64)'])
             for ch in range(2):
-                emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [], MS + [KS, C_OP])
-            emit_block(fh, f"P64_EPILOGUE{pn}", lambda st, pn=pn: st.epilogue_block(pn), [],
-                       ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[ooff] "s"(o_off)', '[osb4] "s"(o_step)'],
-                       exclude=rng("v", LOLD(0), 2) + rng("v", MOLD(0), 2))
+                emit_block(fh, f"P64_REDO{pn}{ch}", lambda st, pn=pn, ch=ch: st.redo_block(pn, ch), [],
+                           ['[skm1] "s"(skm1)', '[j64] "s"(j64)', KS, C_OP])
         emit_block(fh, "P64_CHECK", lambda st: st.check_block(), ['[status] "=&s"(status)'], [])
         for nm, isv in (("P64_DMA_K", False), ("P64_DMA_V", True)):
             emit_block(fh, nm, lambda st, isv=isv: st.dma_block(isv), ['[off] "+s"(dma_off)'],
                        ['[dst] "s"(dma_dst)', '[step] "s"(dma_step)', '[srd] "s"(dma_srd)'])
-        # home registers -> operands: an empty statement whose outputs are pinned to the homes (l, m of the item whose epilogue
-        # has just run)
+        emit_block(fh, "P64_EPILOGUE", lambda st: st.epilogue_block(), [],
+                   ['[wr] "v"(stage_wr)', '[rd] "v"(stage_rd)', '[ovoff] "v"(o_voff)', '[osrd] "s"(o_srd)', '[osb4] "s"(o_step)'],
+                   exclude=rng("v", L(0), 2) + rng("v", M(0), 2))
+        # home registers -> operands: an empty statement whose outputs are pinned to the homes
         fh.write('#define P64_FINAL_F16 ""\n#define P64_FINAL_BF16 ""\n')
-        fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", LOLD(0), 2, "=") + "(l2)", pin("v", MOLD(0), 2, "=") + "(m2)"]) +
+        fh.write("#define P64_FINAL_OPS : " + ", ".join([pin("v", L(0), 2, "=") + "(l2)", pin("v", M(0), 2, "=") + "(m2)"]) +
                  " : : \"memory\"\n")
     print("wrote", os.path.relpath(path, root) if "--out" not in sys.argv else path)
     if "--dev" in sys.argv:
@@ -1076,7 +859,7 @@ def main():
                 def ablated(st, tags=tags):
                     st.ablate = set(tags)
                     return st.steady()
-                emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins, sregs=steady_sregs)
+                emit_block(fh, f"P64_STEADY_ABL{n + 1}", ablated, steady_outs, steady_ins)
         print("wrote", os.path.relpath(dev, root))
 
 

@@ -20,7 +20,5 @@ timeout -k 10 200 python tools/p64_perf.py 2>&1 | grep "^S" | tee $out/${tag}_pe
 if [ -f abv_dev/libmfa_hip.so ]; then
   cp abv_dev/libmfa_hip.so mini-flash-attention_amd/mini_flash_attention/libmfa_hip.so
   for c in 1 0; do timeout -k 10 100 python tools/p64_timeline.py 1024 $c > $out/${tag}_tl_1024_c$c.txt 2>&1; done
-  for w in 0 1 2; do timeout -k 10 100 python tools/p64_timeline.py 1024 1 0 $w > $out/${tag}_tl_1024_c1_w$w.txt 2>&1; done
   grep -v amdgpu.ids $out/${tag}_tl_1024_c1.txt | tail -10; grep -v amdgpu.ids $out/${tag}_tl_1024_c0.txt | tail -10
-  for w in 0 1 2; do grep -A10 "nt= 16" $out/${tag}_tl_1024_c1_w$w.txt | grep "wave\|joint\|first iter"; done
 fi
