@@ -145,17 +145,19 @@ def cpu_baseline(c, budget_s=20.0):
 
 
 def prefill_sweep(mfa, dev):
-    """fp16 B=48 H=24 D=128, S in SWEEP_S, causal and not: TFLOP/s and both roofline fractions, cold and steady"""
+    """fp16 B=48 H=24 D=128, S in SWEEP_S, causal and not: TFLOP/s and both roofline fractions, cold and steady; then the same
+    kernel in bf16 at the headline shape (S=1024 causal) and at its MFMA-bound end (S=4096 non-causal)"""
     out = []
-    for S in SWEEP_S:
-        c = dict(PREFILL, S=S)
+    shapes = [(S, torch.float16, (True, False)) for S in SWEEP_S] + [(1024, torch.bfloat16, (True,)), (4096, torch.bfloat16, (False,))]
+    for S, dtype, causals in shapes:
+        c = dict(PREFILL, S=S, dtype=dtype)
         q, k, v = (torch.randn(c["B"], S, c["H"], c["D"], device=dev, dtype=torch.float32).to(c["dtype"]) for _ in range(3))
-        for causal in (True, False):
+        for causal in causals:
             c["causal"] = causal
             n = max(4, min(40, int(0.25 / (prefill_flops(c) / 0.9e15))))
             cold, steady = cold_and_steady(lambda: mfa.flash_attn_func(q, k, v, causal=causal), steady_n=n,
                                            settle_s=max(0.5, 25 * prefill_flops(c) / 0.9e15))
-            ent = {"S": S, "causal": causal}
+            ent = {"S": S, "causal": causal, "dtype": "bf16" if dtype == torch.bfloat16 else "f16"}
             for nm, ms in (("cold", cold), ("steady", steady)):
                 tf, gb = prefill_flops(c) / ms / 1e9, prefill_bytes(c) / ms / 1e6
                 ent[nm] = {"ms": round(ms, 4), "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK_MFMA_TFLOPS, 4),
@@ -292,7 +294,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(dec_kern_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                      "frac": round(dec_kern_gbps / PEAK_HBM_GBPS, 4), "traffic": measured_traffic("decode"),
                      "traffic_source": "profiles/traffic.json (replayed)",
-                     "kernel": "decode_split_kv_kernel + decode_combine_kernel", "kernel_us": round(dev_ms * 1e3, 2),
+                     "kernel": "decode_split_kv_kernel<BFloat,16,3,dense> (192 workgroups, unsplit: no merge)", "kernel_us": round(dev_ms * 1e3, 2),
                      "algorithmic_bytes": decode_bytes(d)},
     }
 
@@ -307,8 +309,10 @@ def main():
         "unit": "GB/s", "us_per_step": round(gwall / args.steps * 1e6, 2), "dtype": "bf16",
         "config": {"workload": "kv-cache attention bf16 B=24 Sq=1 Skv=8192 Hq=64 Hkv=8 D=128 num_splits=auto"},
         "roofline": {"bound": "hbm", "achieved": round(decode_bytes(g8) / (gev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                     "frac": round(decode_bytes(g8) / (gev_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4), "traffic": None,
-                     "kernel": "prefill_fwd_kernel<MQ> + decode_combine_kernel", "kernel_us": round(gev_ms * 1e3, 2),
+                     "frac": round(decode_bytes(g8) / (gev_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                     "traffic": measured_traffic("kvcache_packed"), "traffic_source": "profiles/traffic.json (replayed)",
+                     "kernel": "prefill_fwd_kernel<BFloat,128,4,0,MQ,STREAM> (key splits) + decode_combine_kernel (1 536 workgroups: "
+                               "the merge stays its own launch at this size)", "kernel_us": round(gev_ms * 1e3, 2),
                      "algorithmic_bytes": decode_bytes(g8)},
     }
     del qg, kc, vc
@@ -323,6 +327,12 @@ def main():
                        "parallelism": f"replicas x{n_gpus} (no collective on the data path)"},
             "roofline": roof, "decode": decode, "kvcache_packed": packed,
         }
+        # the same shape's two regimes, from the sweep (the timed region above runs at settled clocks: see the module docstring)
+        for e in sweeps.get("sweep", []):
+            if e["S"] == c["S"] and e["causal"] == c["causal"] and e["dtype"] == "f16":
+                out["headline_regimes"] = {"cold_tflops": e["cold"]["tflops"], "steady_tflops": e["steady"]["tflops"],
+                                           "note": "cold = first 25 launches after an idle gap; value = the contract's timed region, which "
+                                                   "follows the sweeps and so starts at settled clocks whatever --warmup is"}
         out.update(sweeps)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c)

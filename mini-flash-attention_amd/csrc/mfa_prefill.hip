@@ -661,11 +661,12 @@ static PrefillArgs make_args(const mfa_forward_params& p) {
 
 int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     PrefillArgs a = make_args(p);
-    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip), except for keys that fit three tiles, where its
-    // longer way in and out of a work item costs more than its loop gains (B2 S128 H16: 9.9 vs 7.3 us; equal at S=256).
-    // MFA_PREFILL64=0 forces the general kernel, =2 the 64-row one for everything it serves (tests, tools).
+    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip) from 512 keys up.  Below that its longer way in and
+    // out of a work item costs more than its loop gains (fp16 B48 H24, same box, tools/short_s.py, general / 64-row kernel:
+    // S=128 29 / 44 us, S=256 causal 62.7 / 68.5, S=320 causal 93 / 106, S=384 causal 110 / 121, S=512 causal 157 / 156,
+    // S=512 non-causal 212 / 192).  MFA_PREFILL64=0 forces the general kernel, =2 the 64-row one for everything it serves.
     static const int env_p64 = [] { const char* e = getenv("MFA_PREFILL64"); return e ? atoi(e) : 1; }();
-    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k > 192)) {
+    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k >= 512)) {
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
         if (rc != -2) return rc;
     }

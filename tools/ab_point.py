@@ -4,6 +4,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _knobs; _knobs.apply()
 B, H, D = 48, 24, 128
 for S, causal in ((1024, True), (1024, False), (512, True), (256, True), (2048, True), (4096, False)):
     q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.float16) for _ in range(3))

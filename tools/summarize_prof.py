@@ -67,7 +67,7 @@ def main(tag, name):
                          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 correction)"}
     for k, e in summary["kernels"].items():
         if "hbm_traffic_bytes" in e:
-            key = "prefill" if "prefill64_kernel" in k else ("decode" if "decode_split" in k else None)
+            key = "prefill" if "prefill64_kernel" in k else ("decode" if "decode_split" in k else ("kvcache_packed" if "prefill_fwd_kernel" in k else None))
             if key:
                 traffic[key] = e["hbm_traffic_bytes"]
     with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
