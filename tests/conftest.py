@@ -66,7 +66,7 @@ def assert_close(out, ref, out_dtype=None, atol=ATOL, rtol=RTOL, what="", p_roun
 
 def strict_report(out, ref, name, must_pass=True, why=""):
     """The literal north_star bar: |out - ref_fp32| <= 1e-3 + 1e-3*|ref| -- no half-ulp of the output type, no
-    P-rounding slack.  Records max / mean error and the violating fraction under `name` in parity_r02.json (written
+    P-rounding slack.  Records max / mean error and the violating fraction under `name` in parity_r03.json (written
     beside the other run outputs: gpurun_out/ on the GPU box, copied to profiles/); asserts when must_pass."""
     import json
     o, r = out.detach().float().cpu(), ref.detach().float().cpu()
@@ -80,7 +80,7 @@ def strict_report(out, ref, name, must_pass=True, why=""):
         rec["note"] = why
     outdir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
-    path = os.path.join(outdir, "parity_r02.json")
+    path = os.path.join(outdir, "parity_r03.json")
     try:
         with open(path) as f:
             allrec = json.load(f)
