@@ -199,3 +199,18 @@ def test_kvcache_plan_without_device(capi, oracle):
     assert cnt(batch=16, seqlen_q=1, heads=24, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=4) == 128  # vector kernel
     assert cnt(batch=2, seqlen_q=40, heads=32, kv_heads=4, seqlen_k=4096, head_dim=128, num_splits=4) == 2 * 4 * 3  # packed rows
     assert cnt(batch=2, seqlen_q=1024, heads=32, kv_heads=8, seqlen_k=4096, head_dim=128, num_splits=1) == 0
+
+
+def test_test_hook_and_init_without_device(capi):
+    """mfa_test_set_knob takes the six documented names only; mfa_init needs a device (a negative code and a message here, on a
+    box without one: it must not crash or report success); mfa_debug_last_route starts at 0."""
+    lib = capi.load()
+    lib.mfa_test_set_knob.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    for name in (b"p64_grid", b"group_pairs", b"p64_no_loop", b"nw8", b"mq_stream", b"decode_gt_max"):
+        assert lib.mfa_test_set_knob(name, 0 if name != b"mq_stream" else -1) == capi.MFA_OK
+    assert lib.mfa_test_set_knob(b"no_such_knob", 1) == capi.MFA_ERR_INVALID_ARGUMENT and "no_such_knob" in capi.last_error()
+    assert lib.mfa_test_set_knob(None, 1) == capi.MFA_ERR_INVALID_ARGUMENT
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.mfa_init(-1) < 0 and lib.mfa_init(0) <= 0
+    assert lib.mfa_debug_last_route() == 0 or torch.cuda.is_available()
