@@ -12,11 +12,32 @@ namespace mfa {
 // The split weights stay in two registers per lane (S <= 128), every reduction is a wave shuffle (no LDS, no barrier),
 // and a lane owns column pairs (2*lane, 2*lane+1) + 128*k of the row, so the partial-O reads are 8-byte coalesced
 // and all splits' loads of a column pair are independent.  orow: the row of O (16-bit elements); lse_out: may be null.
-template <typename T>
+// L2LOADS: the partials were written by OTHER workgroups of this launch (the in-kernel merge by the last split to arrive): every
+// load of them is an agent-scope relaxed atomic load (`global_load ... sc1`: served by the XCD's L2, never by this CU's L1, which
+// may hold lines of an earlier launch's partials at the same addresses).  With every split of a row on one XCD (the launch's
+// grid order; mfa_init() checks the premise) and each writer's stores drained (s_waitcnt vmcnt(0)) before its arrival ticket, the
+// L2 holds them when the winner's ticket returns -- no L1 invalidate (`buffer_inv sc1`, ~1.7 us per winning workgroup), which is
+// what made the in-kernel merge lose on launches of more than one round of workgroups.
+template <bool L2LOADS>
+__device__ __forceinline__ float ld_f32(const float* p) {
+    if constexpr (L2LOADS) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool L2LOADS>
+__device__ __forceinline__ float2 ld_f32x2(const float* p) {
+    if constexpr (L2LOADS) {
+        const uint64_t w = __hip_atomic_load((const uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return float2{__builtin_bit_cast(float, (uint32_t)w), __builtin_bit_cast(float, (uint32_t)(w >> 32))};
+    } else {
+        return *(const float2*)p;
+    }
+}
+
+template <typename T, bool L2LOADS = false>
 __device__ __forceinline__ void combine_row(const float* o_acc, const float* lse_acc, int S, int64_t BH, int64_t bh, int D,
                                             char* orow, float* lse_out, int lane) {
-    const float l0 = lane < S ? lse_acc[lane * BH + bh] : -INFINITY;
-    const float l1 = lane + 64 < S ? lse_acc[(lane + 64) * BH + bh] : -INFINITY;
+    const float l0 = lane < S ? ld_f32<L2LOADS>(lse_acc + lane * BH + bh) : -INFINITY;
+    const float l1 = lane + 64 < S ? ld_f32<L2LOADS>(lse_acc + (lane + 64) * BH + bh) : -INFINITY;
     // the first chunk of partial-O loads does not depend on the weights: issue it behind the LSE loads so that the
     // merge pays one memory round trip, not two (it is latency, not bandwidth, that it consists of)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -26,7 +47,12 @@ __device__ __forceinline__ void combine_row(const float* o_acc, const float* lse
     f32x2 first[CH];
 #pragma unroll
     for (int u = 0; u < CH; ++u)
-        first[u] = (u < S && d0 < D) ? *(const f32x2*)(src0 + (int64_t)u * BH * D) : f32x2{0.f, 0.f};
+        if (u < S && d0 < D) {
+            const float2 t = ld_f32x2<L2LOADS>(src0 + (int64_t)u * BH * D);
+            first[u] = f32x2{t.x, t.y};
+        } else {
+            first[u] = f32x2{0.f, 0.f};
+        }
     float M = fmaxf(l0, l1);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) M = fmaxf(M, __shfl_xor(M, off));
@@ -49,7 +75,12 @@ __device__ __forceinline__ void combine_row(const float* o_acc, const float* lse
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 if (dd == 0 && s0 == 0) v[u] = first[u];
-                else v[u] = (col && s0 + u < S) ? *(const f32x2*)(src + (int64_t)(s0 + u) * BH * D) : f32x2{0.f, 0.f};
+                else if (col && s0 + u < S) {
+                    const float2 t = ld_f32x2<L2LOADS>(src + (int64_t)(s0 + u) * BH * D);
+                    v[u] = f32x2{t.x, t.y};
+                } else {
+                    v[u] = f32x2{0.f, 0.f};
+                }
             }
 #pragma unroll
             for (int u = 0; u < CH; ++u) {

@@ -340,14 +340,14 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
         if (threadIdx.x == 0) *flag = atomicAdd(a.split_ctr + row, 1);
         __syncthreads();
         if (*flag != a.num_splits - 1) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // (no acquire fence: the winner reads the partials with L2-served loads, combine_row<T, true>)
         if (threadIdx.x == 0) a.split_ctr[row] = 0;
         const int64_t BH = (int64_t)a.batch * a.heads;
         for (int g = wave; g < GT && g0 + g < a.group; g += kDecodeWaves) {
             const int hq = hk * a.group + g0 + g;
             const int64_t bh = (int64_t)b * a.heads + hq;
             char* orow = (char*)a.o + 2 * (b * a.o_batch_stride + (int64_t)hq * a.o_head_stride);
-            combine_row<T>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, a.lse ? a.lse + bh : nullptr, lane);
+            combine_row<T, true>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, a.lse ? a.lse + bh : nullptr, lane);
         }
     }
 }

@@ -29,8 +29,13 @@ int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream);
 int xcd_premise_probe(int device);
 bool fused_merge_pays(int64_t workgroups, int64_t pbytes);
 int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t workgroups, int64_t pbytes);
+#ifdef MFA_DEV_DECODE_AB // (developer A/B builds: no size gate, tools/ab_decode_map.py measures both sides of it)
+constexpr int64_t kFusedMergeMaxWorkgroups = 1 << 30;
+constexpr int64_t kFusedMergeMaxPartialBytes = 1ll << 40;
+#else
 constexpr int64_t kFusedMergeMaxWorkgroups = 512; // (two per CU: one round of the split kernel)
 constexpr int64_t kFusedMergeMaxPartialBytes = 8 << 20;
+#endif
 inline int64_t partial_bytes(const mfa_forward_params& p) { // (S, B, Sq, H, D) + (S, B, Sq, H) fp32
     return p.num_splits > 1 ? 4ll * p.num_splits * p.batch * p.seqlen_q * p.heads * (p.head_dim + 1) : 0;
 }

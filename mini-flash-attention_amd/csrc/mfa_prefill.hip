@@ -524,7 +524,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
             if (tid == 0) *flag = atomicAdd(a.split_ctr + ctr_idx, 1);
             __syncthreads();
             if (*flag != a.num_splits - 1) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's L1 lines of the partial buffers
+            // (no acquire fence: the winner reads the partials with L2-served loads, combine_row<T, true>)
             if (tid == 0) a.split_ctr[ctr_idx] = 0;
             const int64_t BH = (int64_t)a.batch * sq * a.heads;
             for (int row = m0 + wave; row < min(m0 + BM, nrows); row += NW) {
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
                 const int64_t bh = ((int64_t)b * sq + pos) * a.heads + hh;
                 char* orow = obase + 2 * ((int64_t)pos * a.o_row_stride + (int64_t)(row - pos * G) * a.o_head_stride);
                 float* lse_out = a.lse ? a.lse + ((int64_t)b * a.heads + hh) * sq + pos : nullptr;
-                combine_row<T>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, lse_out, lane);
+                combine_row<T, true>(a.o_acc, a.lse_acc, a.num_splits, BH, bh, D, orow, lse_out, lane);
             }
             return;
         }
