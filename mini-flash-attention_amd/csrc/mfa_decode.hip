@@ -44,7 +44,6 @@ struct DecodeArgs {
     int32_t page_size, page_shift; // page_shift >= 0 when page_size is a power of two
     int32_t max_blocks;
     int32_t num_splits, nchunks;
-    int32_t linear_grid; // workgroup id = row * num_splits + split (no XCD grouping): unsplit launches, see launch_decode
     int32_t seqlens_k_offset; // added to seqlens_k[b] (rows appended just before this launch)
     float scale_log2; // softmax_scale * log2(e)
     // combine only: query positions per batch entry (1 for flash decoding; the packed-row kv-cache kernels of
@@ -85,24 +84,18 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     const int lg = lane / LPR;
     const bool col_ok = c * 8 < a.head_dim;
 
-    // workgroup -> (row = (batch, KV head, head chunk), split): 1-D and XCD-aware -- workgroups bid, bid + 8, ... share an
-    // XCD (round-robin dispatch), XCD x owns a contiguous range of rows and all splits of a row, so that the partials
-    // of a row meet in one L2 (the in-kernel merge below relies on it; mfa_init() checks the premise); launches without
-    // the in-kernel merge take the plain order (linear_grid, see launch_decode)
+    // workgroup -> (row = (batch, KV head, head chunk), split): workgroups bid, bid + 8, ... share an XCD (round-robin dispatch;
+    // mfa_init() checks the premise), and row r runs on XCD r & 7 with ALL its splits -- the partials of a row meet in one L2,
+    // which the in-kernel merge below relies on -- while neighbouring rows (the KV heads of one batch element) sit on different
+    // XCDs, each reading its 256-byte piece of the same K/V rows: unsplit this is the plain order bid = row.  (Round 2 gave XCD
+    // x a CONTIGUOUS range of rows: 3 % slower on config 3, 5 % on the README MHA shape, same box, profiles/r03a_ab_*.)
     int split, row;
-    if (a.linear_grid) {
-        row = blockIdx.x / a.num_splits;
-        split = blockIdx.x - row * a.num_splits;
-        if (row >= a.batch * a.kv_heads * a.nchunks) return;
-    } else {
-        const int R = a.batch * a.kv_heads * a.nchunks;
+    {
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int r8 = R >> 3, rr = R & 7;
-        const int row_begin = x < rr ? x * (r8 + 1) : rr * (r8 + 1) + (x - rr) * r8;
         const int ri = k / a.num_splits;
-        if (ri >= r8 + (x < rr ? 1 : 0)) return;
         split = k - ri * a.num_splits;
-        row = row_begin + ri;
+        row = 8 * ri + x;
+        if (row >= a.batch * a.kv_heads * a.nchunks) return;
     }
     const int b = row / (a.kv_heads * a.nchunks);
     const int hk = (row - b * a.kv_heads * a.nchunks) / a.nchunks;
@@ -455,15 +448,6 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream, bool* merged_
         a.split_ctr = pick_split_counters(p, (size_t)rows, rows * a.num_splits, partial_bytes(one));
     }
     if (merged_in_kernel) *merged_in_kernel = a.split_ctr != nullptr;
-    // Without the in-kernel merge nothing ties a row's splits to one XCD, and then the plain order (workgroup id = row *
-    // splits + split: a (batch, KV head) row next to its neighbour KV heads of the same key rows, the eight XCDs reading
-    // adjacent 256-byte pieces of the same K/V rows) streams faster than XCD-contiguous row ranges: same box, interleaved,
-    // config 3 unsplit 133.0 -> 129.2 us, README MHA Skv8192 440 -> 419 us, 1-3 % at Skv 512-4096
-    // (profiles/r03a_ab_decode_map_and_merge.txt).
-    a.linear_grid = a.split_ctr == nullptr;
-#ifdef MFA_DEV_DECODE_AB // developer A/B builds: the workgroup -> row mapping chosen per launch
-    if (const char* e = getenv("MFA_DEV_DECODE_LINEAR")) a.linear_grid = atoi(e) && !a.split_ctr;
-#endif
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);
 }
 

@@ -122,16 +122,14 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         hk = hq / a.group;
         m0 = mblk * BM;
     } else {
-        // XCD x owns a contiguous range of (batch, KV head) pairs; inside it: pair, split, row block (fastest)
+        // (batch, KV head) pair p runs on XCD p & 7 (workgroups bid, bid + 8, ... share one) with all its key splits and row
+        // blocks -- the in-kernel merge needs a row's partials in one L2 -- and neighbouring pairs on different XCDs
         const int npairs = a.batch * a.kv_heads;
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int p8 = npairs >> 3, r8 = npairs & 7;
-        const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
-        const int pair_count = p8 + (x < r8 ? 1 : 0);
         const int per_pair = a.num_splits * a.mq_row_blocks;
         const int pi = k / per_pair, t = k - pi * per_pair;
-        if (pi >= pair_count) return;
-        const int bk = pair_begin + pi;
+        const int bk = 8 * pi + x;
+        if (bk >= npairs) return;
         b = bk / a.kv_heads;
         hk = bk - b * a.kv_heads;
         split = t / a.mq_row_blocks;

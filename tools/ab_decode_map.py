@@ -1,5 +1,5 @@
 """Same-box A/B of the flash-decoding workgroup -> row mapping and of the in-kernel split merge (developer aid; needs a build
-with MFA_EXTRA_HIPCC_FLAGS=-DMFA_DEV_DECODE_AB, which reads MFA_DEV_DECODE_LINEAR / MFA_FUSED_COMBINE per launch):
+with MFA_EXTRA_HIPCC_FLAGS=-DMFA_DEV_DECODE_AB, which reads MFA_FUSED_COMBINE per launch and has no size gate on the merge):
 interleaved rounds in ONE process, rotating caches, median and min of per-launch HIP-event times.
   python tools/ab_decode_map.py"""
 import os, sys
@@ -55,7 +55,7 @@ def ab(name, run, by, variants, rounds=4):
         print(f"{name:44s} {v:18s} burst us: " + " ".join(f"{x:7.2f}" for x in res[v]) + f"  | min {xs[0]:7.2f} = {by / xs[0] / 1e3:6.0f} GB/s", flush=True)
 
 
-MAP = {"xcd-grouped": {"MFA_DEV_DECODE_LINEAR": "0"}, "linear": {"MFA_DEV_DECODE_LINEAR": "1"}}
+MAP = {"row r on XCD r & 7": {}}  # (round 3a compared the XCD-contiguous order against the plain one here: profiles/r03a_ab_*)
 FUSE = {"fused-merge": {"MFA_FUSED_COMBINE": "1"}, "combine-launch": {"MFA_FUSED_COMBINE": "0"}}
 torch.manual_seed(0)
 run, by = shape(24, 24, 8, 8192, torch.bfloat16, 2)
@@ -65,7 +65,6 @@ for Sk in (512, 1024, 2048, 4096):
     ab(f"GQA bf16 B24 24/8 Skv{Sk} splits=1", run, by, MAP)
 run, by = shape(24, 24, 24, 8192, torch.float16, 2, splits=1)
 ab("README MHA fp16 B24 H24 Skv8192 splits=1", run, by, MAP)
-os.environ["MFA_DEV_DECODE_LINEAR"] = "0"
 run, by = shape(24, 64, 8, 8192, torch.bfloat16, 2)
 ab("packed G=8 bf16 B24 64/8 Skv8192 auto", run, by, FUSE)
 run, by = shape(24, 24, 8, 8192, torch.bfloat16, 2, splits=4)
