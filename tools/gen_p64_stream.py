@@ -151,6 +151,10 @@ def KFR(k):
 
 
 S_T0 = 84  # scalar temporary
+# Non-temporal O stores ("o") and Q requests ("q"): both stream through once, and L2 is exactly as large as the K/V of the (batch,
+# head) pairs an XCD has in flight.  Same-box A/B (profiles/r03_ab_p64_designs.txt): S=512 causal -4.7 %, S=1024 causal -0.6 %, the rest
+# unchanged.  P64_NT overrides for a developer A/B.
+NT = os.environ.get("P64_NT", "oq")
 
 
 def vr(lo, n=1):
@@ -708,7 +712,7 @@ class Stream:
                 self.e(f"ds_read_b128 {vr(R(it), 4)}, %[rd] offset:{it * 4 * 272}")
             for it in range(8):
                 self.e(f"s_waitcnt lgkmcnt({7 - it})")
-                self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen")
+                self.e(f"buffer_store_dwordx4 {vr(R(it), 4)}, %[ovoff], %[osrd], s{S_T0} offen" + (" nt" if "o" in NT else ""))
                 self.e(f"s_add_u32 s{S_T0}, s{S_T0}, %[osb4]")
         return self.out
 
@@ -736,7 +740,7 @@ class Stream:
         for p in range(16):
             self.e(f"s_add_u32 m0, %[dst], {p * 1024}")
             self.e("s_nop 0")
-            self.e(f"buffer_load_dwordx4 {vr(QGO[p & 3])}, %[srd], %[off] offen lds")
+            self.e(f"buffer_load_dwordx4 {vr(QGO[p & 3])}, %[srd], %[off] offen" + (" nt" if "q" in NT else "") + " lds")
             self.e("s_add_u32 %[off], %[off], %[step]")
         return self.out
 
