@@ -47,7 +47,9 @@ def prefill(route, mfa, capi, q, k, v, causal=False, cu_q=None, cu_k=None, max_s
     return o
 
 
-def decode(route, mfa, capi, q, kc, vc, lens=None, block_table=None, num_splits=0, return_partials=False):
+def decode(route, mfa, capi, q, kc, vc, lens=None, block_table=None, num_splits=0, return_partials=False, counters=True, ws=None):
+    """counters=False: no arrival counters are handed over (the merge is decode_combine_kernel's launch); ws: (o_acc, lse_acc)
+    workspaces to reuse instead of fresh ones (the same addresses launch after launch)"""
     if route == "api" and not return_partials:
         return mfa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, block_table=block_table, num_splits=num_splits)
     lib = capi.load()
@@ -58,11 +60,16 @@ def decode(route, mfa, capi, q, kc, vc, lens=None, block_table=None, num_splits=
     lse = torch.empty(B, H, dtype=torch.float32, device=q.device)
     p.softmax_lse_ptr = lse.data_ptr()
     S = p.num_splits
-    o_acc = torch.empty(max(S, 1), B, H, D, dtype=torch.float32, device=q.device)
-    lse_acc = torch.empty(max(S, 1), B, H, dtype=torch.float32, device=q.device)
+    if ws is not None:
+        o_acc, lse_acc = ws
+        assert o_acc.numel() >= max(S, 1) * B * H * D and lse_acc.numel() >= max(S, 1) * B * H
+    else:
+        o_acc = torch.empty(max(S, 1), B, H, D, dtype=torch.float32, device=q.device)
+        lse_acc = torch.empty(max(S, 1), B, H, dtype=torch.float32, device=q.device)
     if S > 1:
         p.oaccum_ptr, p.softmax_lseaccum_ptr = o_acc.data_ptr(), lse_acc.data_ptr()
-        split_counters(capi, p)
+        if counters:
+            split_counters(capi, p)
     _check(capi, lib.mfa_run_flash_attention_with_kv_cache(ctypes.byref(p), _stream()))
     return (o, lse, o_acc, lse_acc, S) if return_partials else o
 

@@ -32,3 +32,34 @@ def test_in_kernel_merge_equals_combine_launch(tmp_path):
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 10
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"{k}: in-kernel merge differs from the combine launch"
+
+
+def test_in_kernel_merge_under_uneven_load_with_reused_workspaces(mfa, capi):
+    """The hand-off the in-kernel merge rests on -- partials written by other workgroups, read by the last one to arrive with
+    L2-served loads and no L1 invalidate -- checked the way such hand-offs fail: the SAME workspace addresses launch after
+    launch (the reader's L1 may still hold the previous launch's partials), new data every launch, another stream keeping
+    part of the chip busy (uneven arrival), every output word compared with the combine launch's on the same partials."""
+    import hip_path as hp
+    lib = capi.load()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(11)
+    B, H, Hk, Sk, D, splits = 8, 24, 8, 4096, 128, 4          # 64 rows x 4 splits = 256 workgroups: merged in the kernel
+    kc = torch.randn(B, Sk, Hk, D, generator=g).to(torch.bfloat16).to(dev)
+    vc = torch.randn(B, Sk, Hk, D, generator=g).to(torch.bfloat16).to(dev)
+    ws = (torch.empty(splits * B * H * D, dtype=torch.float32, device=dev), torch.empty(splits * B * H, dtype=torch.float32, device=dev))
+    ws2 = (torch.empty_like(ws[0]), torch.empty_like(ws[1]))
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device=dev, dtype=torch.bfloat16)
+    stop = torch.zeros(1, device=dev)
+    with torch.cuda.stream(side):                               # a few ms of matmuls on half the chip's worth of work at a time
+        for _ in range(60):
+            stop += (a @ a).float().mean() * 0
+    for it in range(40):
+        q = torch.randn(B, 1, H, D, generator=g).to(torch.bfloat16).to(dev)
+        lens = torch.randint(Sk // 2, Sk + 1, (B,), generator=g).int().to(dev)
+        fused = hp.decode("capi", mfa, capi, q, kc, vc, lens, num_splits=splits, ws=ws)
+        assert lib.mfa_debug_last_route() == capi.MFA_ROUTE_DECODE | capi.MFA_ROUTE_FUSED_MERGE
+        plain = hp.decode("capi", mfa, capi, q, kc, vc, lens, num_splits=splits, ws=ws2, counters=False)
+        assert lib.mfa_debug_last_route() == capi.MFA_ROUTE_DECODE | capi.MFA_ROUTE_COMBINE_LAUNCH
+        assert torch.equal(fused, plain), f"launch {it}: {(fused.float() - plain.float()).abs().max().item():.3e}"
+    torch.cuda.synchronize()
