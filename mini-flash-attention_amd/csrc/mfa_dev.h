@@ -14,6 +14,16 @@
 #define MFA_DEV_ABL(bit) false
 #endif
 
+// non-temporal Q fragment loads / O row stores of prefill_fwd_kernel (A/B switches; the defaults are the measured winners, round 3,
+// same box, fp16 B48 H24 D128: O stores non-temporal S=256 causal 0.062 -> 0.051 ms, S=256 non-causal 0.072 -> 0.061, S=128 / 384
+// causal -4 %, bf16 varlen B16 S2048 -1 %; Q loads non-temporal +10-20 % on the short shapes: profiles/r03_ab_general_nt.txt)
+#ifndef MFA_DEV_NT_Q
+#define MFA_DEV_NT_Q false
+#endif
+#ifndef MFA_DEV_NT_O
+#define MFA_DEV_NT_O true
+#endif
+
 #ifdef MFA_DEV_TIMELINE
 // phase stamps of every workgroup go to the LSE buffer (8 x i64 per workgroup): entry, loop start, loop end, exit,
 // HW_ID, XCC_ID, tiles, marker

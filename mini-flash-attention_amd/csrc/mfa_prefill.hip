@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
     {
         const char* qp = qbase + 2 * row_off(min(qrow, nrows - 1), a.q_row_stride, a.q_head_stride) + 16 * h;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const frag8*)(qp + 32 * ks);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = MFA_DEV_NT_Q ? __builtin_nontemporal_load((const frag8*)(qp + 32 * ks)) : *(const frag8*)(qp + 32 * ks);
     }
 
     // ---- staging: global -> LDS directly (LDS-DMA, global_load_lds_dwordx4), no VGPR round trip --------------
@@ -562,7 +562,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
             const int rr = it * ROWS_PER_IT + rr0;
             const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
             const int grow = wrow0 + rr;
-            if (grow < nrows) *(u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch) = val;
+            if (grow < nrows) {
+                u32x4* dst = (u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch);
+                if (MFA_DEV_NT_O) __builtin_nontemporal_store(val, dst);
+                else *dst = val;
+            }
         }
     } else {
         // CH does not divide 64 (D = 96, 160, ...): walk the 32*CH chunks of the wave linearly
@@ -570,7 +574,11 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
             const int rr = idx / CH, ch = idx - rr * CH;
             const u32x4 val = *(const u32x4*)(so + rr * RB + 16 * (ch ^ k_swz<RB>(rr)));
             const int grow = wrow0 + rr;
-            if (grow < nrows) *(u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch) = val;
+            if (grow < nrows) {
+                u32x4* dst = (u32x4*)(obase + 2 * row_off(grow, a.o_row_stride, a.o_head_stride) + 16 * ch);
+                if (MFA_DEV_NT_O) __builtin_nontemporal_store(val, dst);
+                else *dst = val;
+            }
         }
     }
     MFA_DEV_STAMP_FLUSH(a.lse, tid, nt);
