@@ -667,12 +667,13 @@ static PrefillArgs make_args(const mfa_forward_params& p) {
 
 int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     PrefillArgs a = make_args(p);
-    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip) from 512 keys up.  Below that its longer way in and
-    // out of a work item costs more than its loop gains (fp16 B48 H24, same box, tools/short_s.py, general / 64-row kernel:
-    // S=128 29 / 44 us, S=256 causal 62.7 / 68.5, S=320 causal 93 / 106, S=384 causal 110 / 121, S=512 causal 157 / 156,
-    // S=512 non-causal 212 / 192).  MFA_PREFILL64=0 forces the general kernel, =2 the 64-row one for everything it serves.
+    // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip) from 512 keys up with a right bound (causal), from
+    // 384 without.  Below that its longer way in and out of a work item costs more than its loop gains (fp16 B48 H24, same box,
+    // tools/short_s.py, general / 64-row kernel, us: S=128 27 / 43, S=256 causal 51 / 67, non-causal 59 / 68, S=320 88 / 102
+    // and 105 / 107, S=384 106 / 112 and 131 / 122, S=512 153 / 147 and 209 / 187).  MFA_PREFILL64=0 forces the general
+    // kernel, =2 the 64-row one for everything it serves.
     static const int env_p64 = [] { const char* e = getenv("MFA_PREFILL64"); return e ? atoi(e) : 1; }();
-    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k >= 512)) {
+    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k >= (a.has_hi ? 512 : 384))) {
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
         if (rc != -2) return rc;
     }
