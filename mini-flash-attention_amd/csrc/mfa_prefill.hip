@@ -247,9 +247,19 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
     const int64_t k_page_bytes = PG == 1 ? in_vgpr(2 * a.k_block_stride) : 0, v_page_bytes = PG == 1 ? in_vgpr(2 * a.v_block_stride) : 0;
     int pid_n[PG == 1 ? NI : 1];
     const char *kpage_n = nullptr, *vpage_n = nullptr; // PG == 2: page bases of the next tile to be fetched
+    int tab_chunk = -1, tab_v = 0;                     // PG == 2: 64 block-table entries in a VGPR (see load_pids)
     auto load_pids = [&](int j) {
-        if constexpr (PG == 2) { // one page per tile: a wave-uniform (scalar) block-table load
-            const int64_t pid = __builtin_amdgcn_readfirstlane(table[min((j * kBN) >> a.page_shift, a.max_blocks - 1)]);
+        if constexpr (PG == 2) { // one page per tile.  The batch element's block-table row sits in ONE VGPR, 64 entries at a
+            // time (lane i: entry 64 * chunk + i), and a tile's page id is a v_readlane: a scalar table load per tile is
+            // waited for with lgkmcnt(0), which also drains the LDS fragment reads in flight (round 3: paged varlen prefill
+            // bf16 B16 S2048 24/8 causal, page 256: 0.50 ms with the per-tile load)
+            const int pg = min((j * kBN) >> a.page_shift, a.max_blocks - 1);
+            const int chunk = pg >> 6;
+            if (chunk != tab_chunk) { // (wave-uniform; once per 64 pages: the vector load's wait also drains DMA in flight)
+                tab_chunk = chunk;
+                tab_v = table[min(64 * chunk + lane, a.max_blocks - 1)];
+            }
+            const int64_t pid = __builtin_amdgcn_readlane(tab_v, pg & 63);
             kpage_n = kbase + 2 * pid * a.k_block_stride;
             vpage_n = vbase + 2 * pid * a.v_block_stride;
         } else if constexpr (PG == 1) {
@@ -275,9 +285,18 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         if constexpr (PG == 2) {
             // the tile's page id is wave-uniform: page base on the scalar side, the row inside the page as a 32-bit
             // lane offset (the dense path's addressing; rows past the last key clamp to it, in the same page)
-            const uint32_t in = (uint32_t)(min(j * kBN + row + srow, last_key) & (a.page_size - 1));
-            if (is_v) lds_dma16<DMA_NT>(vpage_n, in * v_sb + 16 * s_vch, dst);
-            else lds_dma16<DMA_NT>(kpage_n, in * k_sb + 16 * k_src_chunk(srow + row), dst);
+            // All of it but one add and one min per piece is scalar: r0 = the piece's first row inside the page, lim = the
+            // last key's row there (the page's last row when the last key lies in a later page).  A per-lane row * pitch
+            // is a quarter-rate v_mul_lo per piece, which this VALU-co-limited loop does not hide.
+            const int key0 = j * kBN + row;
+            const uint32_t r0 = (uint32_t)(key0 & (a.page_size - 1));
+            const uint32_t lim = (uint32_t)min(last_key - (key0 - (int)r0), a.page_size - 1);
+            if (is_v) {
+                lds_dma16<DMA_NT>(vpage_n, min(r0 * v_sb + v_go, lim * v_sb + 16 * s_vch), dst);
+            } else {
+                const int kd = KSWZ_FIXED ? 0 : 16 * (k_src_chunk(srow + row) - s_kch);
+                lds_dma16<DMA_NT>(kpage_n, min(r0 * k_sb + k_go, lim * k_sb + 16 * s_kch) + kd, dst);
+            }
         } else if constexpr (PG == 1) {
             // page ids were looked up one tile earlier (pid_n): a block-table load right here would be waited for by
             // the compiler with a vmcnt that also drains every DMA piece issued before it
