@@ -112,7 +112,9 @@ typedef struct mfa_forward_params {
                                    window_size_* fields above stay accepted-and-ignored, as upstream         */
     int32_t local_window_left;  /* keys >= row + off - left  (-1 = unbounded)                  */
     int32_t local_window_right; /* keys <= row + off + right (-1 = unbounded)                  */
-    int64_t total_q;            /* varlen: rows of q (layout of the LSE output)                */
+    int64_t total_q;            /* varlen: rows of q (layout of the LSE output; 0 = not given, allowed without an LSE.
+                                   The launcher also reads the batch's mean length off it: an even batch of long
+                                   sequences, head dim 128, takes the 64-rows-per-wave kernel)                */
     int32_t seqlens_k_offset;   /* added to every seqlens_k[b] (keys just appended by mfa_kvcache_append)     */
     int32_t reserved;
     /* kv-cache entry with num_splits > 1, optional: arrival counters for the IN-KERNEL merge of the key splits (the last
@@ -184,14 +186,15 @@ int mfa_init(int device);
 size_t mfa_kvcache_counter_count(const mfa_forward_params* p);
 #define MFA_SPLIT_COUNTERS_MAX 65536
 
-/* Which kernels the calling thread's last successful mfa_run_flash_attention_with_kv_cache() launched: a test / tracing
- * aid (the reference has no counterpart).  MFA_ROUTE_* bits. */
+/* Which kernels the calling thread's last successful mfa_run_flash_attention_with_kv_cache() or
+ * mfa_run_flash_attention_forward() launched: a test / tracing aid (the reference has no counterpart).  MFA_ROUTE_* bits. */
 enum {
     MFA_ROUTE_DECODE = 1,       /* vector flash-decoding kernel (mfa_decode.hip)                         */
     MFA_ROUTE_PACKED = 2,       /* packed-row MFMA kernel (MQ instances, mfa_prefill.hip)                */
-    MFA_ROUTE_PREFILL = 4,      /* per-head prefill kernel over the cache                                */
+    MFA_ROUTE_PREFILL = 4,      /* per-head prefill kernel (the forward entry; the kv-cache entry for seqlen_q > 1) */
     MFA_ROUTE_COMBINE_LAUNCH = 8, /* split merge as decode_combine_kernel's own launch                  */
-    MFA_ROUTE_FUSED_MERGE = 16  /* split merge inside the split kernel (split_counters used)             */
+    MFA_ROUTE_FUSED_MERGE = 16, /* split merge inside the split kernel (split_counters used)             */
+    MFA_ROUTE_PREFILL64 = 32    /* with MFA_ROUTE_PREFILL: the 64-rows-per-wave kernel (mfa_prefill64.hip)  */
 };
 int mfa_debug_last_route(void);
 

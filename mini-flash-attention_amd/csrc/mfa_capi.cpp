@@ -20,7 +20,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local int g_last_route = 0; // MFA_ROUTE_* bits of this thread's last successful kv-cache call
+thread_local int g_last_route = 0; // MFA_ROUTE_* bits of this thread's last successful kv-cache / forward call
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -218,7 +218,9 @@ int mfa_run_flash_attention_forward(const mfa_forward_params* p, void* hip_strea
     if ((p->cu_seqlens_q == nullptr) != (p->cu_seqlens_k == nullptr))
         return fail(MFA_ERR_INVALID_ARGUMENT, "cu_seqlens_q and cu_seqlens_k must be given together");
     if (p->batch == 0 || p->seqlen_q == 0) return MFA_OK;
-    const int rc = mfa::launch_prefill(*p, static_cast<hipStream_t>(hip_stream));
+    bool p64 = false;
+    const int rc = mfa::launch_prefill(*p, static_cast<hipStream_t>(hip_stream), &p64);
+    if (rc == 0) g_last_route = MFA_ROUTE_PREFILL | (p64 ? MFA_ROUTE_PREFILL64 : 0);
     if (rc == -2) return fail(MFA_ERR_UNSUPPORTED, "no prefill kernel for head_dim %d", p->head_dim);
     if (rc) return fail(MFA_ERR_LAUNCH, "prefill launch failed: %s", hipGetErrorString(hipGetLastError()));
     return MFA_OK;
@@ -347,9 +349,10 @@ int mfa_run_flash_attention_with_kv_cache(const mfa_forward_params* p, void* hip
         if (p->head_dim % 32 != 0)
             return fail(MFA_ERR_UNSUPPORTED, "kv-cache attention with seqlen_q > 1 needs head_dim %% 32 == 0 (got %d)", p->head_dim);
         if (p->num_splits > 1) return fail(MFA_ERR_INVALID_ARGUMENT, "this shape runs unsplit: ask mfa_kvcache_plan for num_splits");
-        const int rc = mfa::launch_prefill(q, stream);
+        bool p64 = false;
+        const int rc = mfa::launch_prefill(q, stream, &p64);
         if (rc) return fail(MFA_ERR_LAUNCH, "kv-cache prefill launch failed: %s", hipGetErrorString(hipGetLastError()));
-        g_last_route = MFA_ROUTE_PREFILL;
+        g_last_route = MFA_ROUTE_PREFILL | (p64 ? MFA_ROUTE_PREFILL64 : 0);
         return MFA_OK;
     }
     bool fused = false;

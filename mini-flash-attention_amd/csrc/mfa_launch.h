@@ -10,7 +10,7 @@
 namespace mfa {
 
 // Prefill / varlen / paged prefill (replaces run_mha_prefill, reference csrc/mfa/flash.cu:11-34).
-int launch_prefill(const mfa_forward_params& p, hipStream_t stream);
+int launch_prefill(const mfa_forward_params& p, hipStream_t stream, bool* used_prefill64 = nullptr);
 
 // Decode + optional combine (replaces run_mha_decode, reference csrc/mfa/flash.cu:36-71).  *merged_in_kernel (may be
 // null): whether the split merge ran inside the split kernel (false: unsplit, or decode_combine_kernel launched behind).

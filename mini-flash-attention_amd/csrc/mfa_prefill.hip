@@ -684,7 +684,7 @@ static PrefillArgs make_args(const mfa_forward_params& p) {
     return a;
 }
 
-int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
+int launch_prefill(const mfa_forward_params& p, hipStream_t stream, bool* used_prefill64) {
     PrefillArgs a = make_args(p);
     // head dim 128, dense: the 64-rows-per-wave kernel (mfa_prefill64.hip) from 512 keys up with a right bound (causal), from
     // 384 without.  Below that its longer way in and out of a work item costs more than its loop gains (fp16 B48 H24, same box,
@@ -692,9 +692,20 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream) {
     // and 105 / 107, S=384 106 / 112 and 131 / 122, S=512 153 / 147 and 209 / 187).  MFA_PREFILL64=0 forces the general
     // kernel, =2 the 64-row one for everything it serves.
     static const int env_p64 = [] { const char* e = getenv("MFA_PREFILL64"); return e ? atoi(e) : 1; }();
-    if (env_p64 == 2 || (env_p64 == 1 && a.seqlen_k >= (a.has_hi ? 512 : 384))) {
+    // Packed variable-length batches take it too (round 3) when they are even enough for its static schedule.  The lengths
+    // are device data, so the launcher goes by the mean query length total_q / batch: at least 0.9 of max_seqlen_q.  Ragged
+    // batches keep the general kernel, whose workgroups the hardware deals out as CUs fall free (bf16 H24/8 causal,
+    // tools/varlen_point.py, general / 64-row kernel ms: 16 x 2048 0.472 / 0.417, 48 x 1024 0.421 / 0.387; lengths
+    // 1024..2048 0.477 / 0.505, 512..4096 0.774 / 0.902, 128..4096 log-uniform 1.21 / 1.61).
+    const int p64_from = a.has_hi ? 512 : 384;
+    bool p64_fits = a.seqlen_k >= p64_from;
+    if (a.cu_q) p64_fits = p64_fits && a.batch > 0 && a.seqlen_q >= p64_from && 10 * a.total_q >= 9 * (int64_t)a.batch * a.seqlen_q;
+    if (env_p64 == 2 || (env_p64 == 1 && p64_fits)) {
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
-        if (rc != -2) return rc;
+        if (rc != -2) {
+            if (used_prefill64) *used_prefill64 = rc == 0;
+            return rc;
+        }
     }
     return p.is_bf16 ? launch_prefill_d<BFloat>(a, stream) : launch_prefill_d<Half>(a, stream);
 }

@@ -226,6 +226,7 @@ at::Tensor flash_attention_varlen_forward(const at::Tensor& q, const at::Tensor&
     set_windows(p, window_size_left, window_size_right, max_seqlen_k);
 
     MFA_CHECK_SHAPE(q, total_q, num_heads, head_dim);
+    p.total_q = total_q; // (the launcher reads how even the batch is off total_q / batch against max_seqlen_q)
     if (block_table_.has_value()) {
         TORCH_CHECK(k.dim() == 4 && v.dim() == 4, "paged k, v must be (num_blocks, page_block_size, heads_k, head_dim)");
         const int num_blocks = k.size(0), page_block_size = k.size(1);

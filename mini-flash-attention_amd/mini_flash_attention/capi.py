@@ -17,7 +17,7 @@ MFA_ERR_UNSUPPORTED = -2
 MFA_ERR_LAUNCH = -3
 MFA_ERR_WORKSPACE = -4
 MFA_SPLIT_COUNTERS_MAX = 65536
-MFA_ROUTE_DECODE, MFA_ROUTE_PACKED, MFA_ROUTE_PREFILL, MFA_ROUTE_COMBINE_LAUNCH, MFA_ROUTE_FUSED_MERGE = 1, 2, 4, 8, 16
+MFA_ROUTE_DECODE, MFA_ROUTE_PACKED, MFA_ROUTE_PREFILL, MFA_ROUTE_COMBINE_LAUNCH, MFA_ROUTE_FUSED_MERGE, MFA_ROUTE_PREFILL64 = 1, 2, 4, 8, 16, 32
 
 _i64, _i32, _f32, _vp = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p
 

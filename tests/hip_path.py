@@ -43,6 +43,8 @@ def prefill(route, mfa, capi, q, k, v, causal=False, cu_q=None, cu_k=None, max_s
         return mfa.flash_attn_varlen_func(q, k, v, cu_q, cu_k, max_sq, max_sk, causal=causal, block_table=block_table)
     o = torch.empty_like(q)
     p = fill_params(q, k, v, o, causal=causal, cu_q=cu_q, cu_k=cu_k, max_sq=max_sq, max_sk=max_sk, block_table=block_table)
+    if cu_q is not None:
+        p.total_q = q.size(0)  # (as the torch binding does: lets the launcher see how even the batch is)
     _check(capi, capi.load().mfa_run_flash_attention_forward(ctypes.byref(p), _stream()))
     return o
 

@@ -9,7 +9,7 @@
 extern "C" int mfa_test_launch_count = 0;
 
 namespace mfa {
-int launch_prefill(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
+int launch_prefill(const mfa_forward_params&, hipStream_t, bool*) { ++mfa_test_launch_count; return 0; }
 int launch_decode(const mfa_forward_params&, hipStream_t, bool* f) { ++mfa_test_launch_count; if (f) *f = false; return 0; }
 int launch_kvcache_packed(const mfa_forward_params&, hipStream_t, bool* f) { ++mfa_test_launch_count; if (f) *f = false; return 0; }
 int launch_decode_combine(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }

@@ -148,6 +148,24 @@ def test_varlen_mixed_lengths(mfa, capi, oracle, dtype):
                 assert_close(out, ref, p_rounded=True, what=f"varlen {lens[:4]} {route} causal={causal}")
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_varlen_even_batches_take_the_64_row_kernel(mfa, capi, oracle, dtype):
+    """Head dim 128, mean length >= 0.9 max: the launcher hands the batch to prefill64_kernel's varlen instances (the route
+    query says so); a ragged batch of the same sizes stays on the general kernel.  Values against per-sequence SDPA-fp32."""
+    lib = capi.load()
+    for lens, want64 in (([512] * 6, True), ([640, 600, 620, 577], True), ([1024, 1000, 1024], True), ([640, 100, 620, 64], False)):
+        tot = sum(lens)
+        cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
+        q, k, v = rnd(tot, 6, 128, dtype=dtype, seed=1), rnd(tot, 2, 128, dtype=dtype, seed=2), rnd(tot, 2, 128, dtype=dtype, seed=3)
+        for causal in (False, True):
+            ref = oracle.sdpa_varlen(q.cpu(), k.cpu(), v.cpu(), cu.cpu(), cu.cpu(), causal)
+            for route in hp.ROUTES:
+                out = hp.prefill(route, mfa, capi, q, k, v, causal, cu_q=cu, cu_k=cu, max_sq=max(lens), max_sk=max(lens))
+                bits = lib.mfa_debug_last_route()
+                assert bits & capi.MFA_ROUTE_PREFILL and bool(bits & capi.MFA_ROUTE_PREFILL64) == want64, (lens, route, bits)
+                assert_close(out, ref, p_rounded=True, what=f"varlen {lens} {route} causal={causal}")
+
+
 def test_varlen_different_q_and_k_lengths(mfa, capi, oracle):
     """total_k != total_q is accepted (the reference insists on equality, api.cpp:259-260)."""
     lq, lk = [3, 70, 128], [200, 64, 129]

@@ -1,4 +1,4 @@
-"""Quick parity + timing check of the 64-rows-per-wave prefill kernel against the general kernel and SDPA-fp32 (GPU box).
+"""Quick parity + timing check of the 64-rows-per-wave prefill kernel (dense and packed varlen) against SDPA-fp32 (GPU box).
   python tools/p64_check.py [quick]"""
 import os, subprocess, sys, time
 import torch
@@ -38,6 +38,51 @@ for dt in (torch.float16, torch.bfloat16):
             ok = bool((err <= tol).all()) and bool(torch.isfinite(o).all())
             bad += not ok
             print(f"{str(dt)[6:]:9s} B{B} Sq{Sq} Sk{Sk} H{H}/{Hk} causal={int(causal)}: max {err.max().item():.2e} mean {err.mean().item():.2e} {'ok' if ok else 'FAIL'}", flush=True)
+# packed variable-length batches on the same kernel (its VL instances): per-sequence SDPA-fp32, O and LSE; ragged lengths,
+# lengths below one row block, different query / key lengths with and without the (top-left) causal bound, sequences with no
+# rows and with no keys; the route query says which kernel ran
+from mini_flash_attention import capi
+_lib = capi.load()
+varlen_cases = [([64], [64]), ([1, 77, 300, 512, 1000], None), ([256] * 4, None), ([1024, 1024], None), ([100, 257], [333, 64]),
+                ([300, 100], [200, 400]), ([513, 0, 129], [513, 70, 129]), ([40, 260, 5], [40, 0, 700])]
+for dt in (torch.float16, torch.bfloat16):
+    for (lq, lk) in varlen_cases:
+        for causal in (False, True):
+            lk_ = lk or lq
+            if causal and lk and 0 in lk:  # (a causal row with no key is the general kernel's business; SDPA gives NaN)
+                continue
+            H, Hk = 4, 2
+            q = torch.randn(sum(lq), H, 128, device="cuda").to(dt)
+            k = torch.randn(sum(lk_), Hk, 128, device="cuda").to(dt)
+            v = torch.randn(sum(lk_), Hk, 128, device="cuda").to(dt)
+            cq = torch.tensor([0] + lq, device="cuda").cumsum(0).int()
+            ck = torch.tensor([0] + lk_, device="cuda").cumsum(0).int()
+            o, lse = mfa.flash_attn_varlen_func(q, k, v, cq, ck, max(lq), max(lk_), causal=causal, return_softmax_lse=True)
+            route = _lib.mfa_debug_last_route()
+            torch.cuda.synchronize()
+            assert route & capi.MFA_ROUTE_PREFILL64, route
+            ok, worst = bool(torch.isfinite(o).all()), 0.0
+            for i in range(len(lq)):
+                q0, k0 = int(cq[i]), int(ck[i])
+                if lq[i] == 0:
+                    continue
+                oi, li = o[q0:q0 + lq[i]].float(), lse[:, q0:q0 + lq[i]]
+                if lk_[i] == 0:
+                    ok = ok and bool((oi == 0).all()) and bool(torch.isinf(li).all() and (li < 0).all())
+                    continue
+                qf = q[q0:q0 + lq[i]].float().transpose(0, 1)
+                kf = k[k0:k0 + lk_[i]].float().transpose(0, 1).repeat_interleave(H // Hk, 0)
+                vf = v[k0:k0 + lk_[i]].float().transpose(0, 1).repeat_interleave(H // Hk, 0)
+                sc = qf @ kf.transpose(1, 2) / 128 ** 0.5
+                if causal:  # top-left: key <= row
+                    sc = sc.masked_fill(torch.arange(lk_[i], device="cuda")[None, :] > torch.arange(lq[i], device="cuda")[:, None], float("-inf"))
+                r = (torch.softmax(sc, -1) @ vf).transpose(0, 1)
+                err = (oi - r).abs()
+                tol = 1e-3 + (1e-3 + (2 ** -11 if dt == torch.float16 else 2 ** -8)) * r.abs() + (3e-3 if dt == torch.bfloat16 else 0)
+                ok = ok and bool((err <= tol).all()) and bool((li - torch.logsumexp(sc, -1)).abs().max() < 2e-3)
+                worst = max(worst, err.max().item())
+            bad += not ok
+            print(f"{str(dt)[6:]:9s} varlen q{lq} k{lk_} causal={int(causal)}: max {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
 print("FAILURES:", bad, flush=True)
 if bad:
     sys.exit(1)
