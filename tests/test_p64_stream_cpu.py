@@ -48,7 +48,7 @@ def _kernels(asm):
 
 def test_both_element_types_assemble_within_the_register_file(p64_asm):
     ks = _kernels(p64_asm)
-    assert len(ks) == 4 and any("4Half" in k for k in ks) and any("6BFloat" in k for k in ks), list(ks)
+    assert len(ks) == 6 and any("4Half" in k for k in ks) and any("6BFloat" in k for k in ks), list(ks)
     for name, (_, res) in ks.items():
         g = lambda key: int(re.search(r"\.amdhsa_" + key + r"\s+(\d+)", res).group(1))
         assert g("next_free_vgpr") <= 512 and g("private_segment_fixed_size") == 0, (name, g("next_free_vgpr"))

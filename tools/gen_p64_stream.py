@@ -23,6 +23,7 @@ numbers below are RELATIVE to VB / AB.  hipcc allocates from register 0 upwards 
     v[158:159], v[164:165]  DMA lane offsets of the Q staging, by piece & 3
     v[160:161]  l0, l1      v[162:163]  lt0, lt1 (row sums of the tile in flight)
     v[166:167]  row + hi of chain 0 / 1 (mask bound; 0x3fffffff without a right bound)      v168  4*h
+    v169        paged K/V (P64_STEADY_PG): the sequence's block-table row, lane i = entry i (P64_SETTAB)
     v[170:171]  -m*c of chain 0 / 1 (addend of the softmax fma)      v[172:173]  m0, m1 (max of the raw scores)
     v[174:179]  temporaries
     a[0:127]    O blocks: chain c, column block d: a[(4c+d)*16]
@@ -62,6 +63,11 @@ Blocks (P = parity of a tile's S buffer, C = chain); scalar operands are named i
                         the LDS reads and the DMA pieces of K(j+2), V(j+1) in the gaps between the MFMAs, fragment reads
                         handed over between phases; leaves at jend (status 0) or when a tile's row sums fail the test
                         (status 1, tile j's phases done, its sums not yet accepted)
+    P64_STEADY_PG       the same loop over a PAGED K/V cache (pages of 64 << %[tps] keys, at most 64 per sequence): a tile's
+                        descriptor (page base = pool + table entry * block bytes, records = the page's rows that exist) and
+                        running offset are rebuilt on the scalar side, one instruction per gap of phase X, for the tile
+                        the NEXT iteration stages; the descriptors live in s[88:91] (K) and s[92:95] (V)
+    P64_SETTAB          a work item's block-table row -> its home register
     P64_X{P}_SM         phase X alone: scores of the K tile in slot %[kslot] into buffer P, softmax steps 32..63 of buffer P^1
     P64_Y{P}[_SM]       phase Y alone: O += V.P, P in buffer P, V tile in slot %[vslot] [softmax steps 0..31 of buffer P^1]
     P64_LAST{P}[_M]     a wave's last tile (scores in buffer P) in one piece: phase Y of the tile before with the first half
@@ -124,6 +130,8 @@ def QHI(c):
 
 
 H4 = 168
+TAB = 169  # paged K/V: block-table row of the work item's sequence
+K_SRD, V_SRD = 88, 92  # P64_STEADY_PG: physical SGPR quads of the running K / V descriptors
 
 
 def MC(c):
@@ -174,6 +182,32 @@ class Stream:
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.lds_log = []
         self.ablate = set()  # developer timing builds: "dma", "sm", "lds" leave that part of the steady loop out
+        self.paged = False   # P64_STEADY_PG
+
+    def page_update(self, is_v, ahead):
+        """Descriptor and running offset of the V / K tile j + ahead of a paged cache (s84..s87 temporaries): page index
+        (clamped to the sequence's last page), table entry out of the TAB register, 64-bit page base, records = rows of
+        the page that exist x row pitch (rows past the last key read as zeros, as the dense descriptors arrange), offset =
+        the tile's first row inside the page."""
+        srd = V_SRD if is_v else K_SRD
+        pool = "vpool" if is_v else "kpool"
+        off = "%[voff]" if is_v else "%[koff]"
+        return [
+            [f"s_add_u32 s84, %[j], {ahead}"],
+            ["s_lshr_b32 s85, s84, %[tps]"],
+            ["s_min_u32 s85, s85, %[maxpg]"],
+            [f"v_readlane_b32 s86, {vr(TAB)}, s85"],
+            ["s_mul_hi_u32 s87, s86, %[blk]"],
+            ["s_mul_i32 s86, s86, %[blk]"],
+            [f"s_add_u32 s{srd}, %[{pool}lo], s86", f"s_addc_u32 s{srd + 1}, %[{pool}hi], s87"],
+            ["s_lshl_b32 s86, s85, %[pshift]"],
+            ["s_sub_u32 s86, %[kvrows], s86"],
+            ["s_min_u32 s86, s86, %[pagerows]"],
+            [f"s_mul_i32 s{srd + 2}, s86, %[sb]"],
+            ["s_and_b32 s86, s84, %[tppm1]"],
+            ["s_lshl_b32 s86, s86, 6"],
+            [f"s_mul_i32 {off}, s86, %[sb]"],
+        ]
 
     def e(self, s):
         self.out.append(s)
@@ -317,13 +351,18 @@ class Stream:
             elif ch == 0:
                 self.k_read(f + PF - 16, 1, ks_)
             if dma:
+                ksrd, vsrd = (f"s[{K_SRD}:{K_SRD + 3}]", f"s[{V_SRD}:{V_SRD + 3}]") if self.paged else ("%[ksrd]", "%[vsrd]")
                 if pc < NI:
-                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, %[ksrd], %[koff] offen lds")
+                    self.e(f"buffer_load_dwordx4 {vr(V_KGO)}, {ksrd}, %[koff] offen lds")
                     self.e("s_add_u32 %[koff], %[koff], %[k16]")
                 else:
-                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, %[vsrd], %[voff] offen lds")
+                    self.e(f"buffer_load_dwordx4 {vr(V_VGO)}, {vsrd}, %[voff] offen lds")
                     self.e("s_add_u32 %[voff], %[voff], %[v16]")
         # ---- phase X: S^T = K.Q^T of tile j+1 into the buffer P^1 (slot t: chain t & 1, K fragment t >> 1 = 8*kb + ks)
+        # paged: this iteration's pieces are out; the descriptors / offsets of the tiles the NEXT iteration stages (K(j+3),
+        # V(j+2)), one step per gap, all ahead of the j increment at t == 30
+        pg_steps = (self.page_update(False, 3) + self.page_update(True, 2)) if self.paged else []
+        assert len(pg_steps) <= 30
         for t in range(32):
             ch, f = t & 1, t >> 1
             self.mfma_x(P ^ 1, t)
@@ -333,6 +372,9 @@ class Stream:
                     self.wait_frag("K", 1, f + 1)
                 else:
                     self.wait_frag("V", 2, 0)
+            if t < len(pg_steps):
+                for ln in pg_steps[t]:
+                    self.e(ln)
             self.sm_step(P, 32 + t)
             if f + PF <= 15:
                 if ch == 0:
@@ -357,6 +399,12 @@ class Stream:
         self.e("s_cmp_ge_i32 %[j], %[jend]")
         self.e("s_cbranch_scc1 9f")
         self.pads()
+        if self.paged:  # the descriptors / offsets of the tiles the first iteration stages: K(j+2), V(j+1)
+            for is_v, ahead in ((False, 2), (True, 1)):
+                for step in self.page_update(is_v, ahead):
+                    for ln in step:
+                        self.e(ln)
+                self.e(f"s_mov_b32 s{(V_SRD if is_v else K_SRD) + 3}, 0x00020000")
         for i in range(1, 6):
             self.e(f"s_cmp_eq_u32 %[entry], {i}")
             self.e(f"s_cbranch_scc1 2{i}f")
@@ -788,7 +836,7 @@ def pin(kind, lo, n, mode=""):
     return f'"{mode}{{{kind}[{lo}:{lo + n - 1}]}}"'
 
 
-def emit_block(fh, name, lines_of, outs, ins, exclude=()):
+def emit_block(fh, name, lines_of, outs, ins, exclude=(), extra_clobbers=()):
     n = 0
     for suffix, f16 in (("F16", True), ("BF16", False)):
         lines = lines_of(Stream(f16))
@@ -798,7 +846,7 @@ def emit_block(fh, name, lines_of, outs, ins, exclude=()):
         fh.write('    ""\n')
         n = sum(1 for ln in lines if not ln.startswith(';') and not ln.endswith(':'))
     fh.write(f"// {name}: {n} instructions\n")
-    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude)) + "\n\n")
+    fh.write(f"#define {name}_OPS : " + ", ".join(outs) + " : " + ", ".join(ins) + " : " + clob(all_regs(exclude) + list(extra_clobbers)) + "\n\n")
 
 
 def main():
@@ -830,6 +878,18 @@ def main():
         emit_block(fh, "P64_FIRST0", lambda st: st.first_block(0), [], [C_OP])
         emit_block(fh, "P64_X1_FIRST0", lambda st: st.x_first_block(), [], [KS, C_OP])
         emit_block(fh, "P64_STEADY", lambda st: st.steady(), steady_outs, steady_ins)
+
+        def steady_paged(st):
+            st.paged = True
+            return st.steady()
+        emit_block(fh, "P64_STEADY_PG", steady_paged,
+                   ['[j] "+s"(j)', '[koff] "=&s"(k_off)', '[voff] "=&s"(v_off)', '[status] "=&s"(status)'],
+                   ['[jend] "s"(jend)', '[entry] "s"(entry)', '[k16] "s"(k_step)', '[v16] "s"(v_step)', '[dst0] "s"(dma_dst0)', C_OP,
+                    '[tps] "s"(pg_tps)', '[pshift] "s"(pg_shift)', '[tppm1] "s"(pg_tppm1)', '[pagerows] "s"(pg_rows)',
+                    '[maxpg] "s"(pg_max)', '[kvrows] "s"(pg_kvrows)', '[kpoollo] "s"(pg_kpool_lo)', '[kpoolhi] "s"(pg_kpool_hi)',
+                    '[vpoollo] "s"(pg_vpool_lo)', '[vpoolhi] "s"(pg_vpool_hi)', '[blk] "s"(pg_blk)', '[sb] "s"(k_sb)'],
+                   extra_clobbers=[f"s{i}" for i in range(86, 96)])
+        emit_block(fh, "P64_SETTAB", lambda st: [f"v_mov_b32 {vr(TAB)}, %[tab]"], [], ['[tab] "v"(tab_cur)'])
         for pn in range(2):
             emit_block(fh, f"P64_X{pn}_SM", lambda st, pn=pn: st.phase_x(pn, True), [], [KS, C_OP])
             emit_block(fh, f"P64_Y{pn}", lambda st, pn=pn: st.phase_y(pn, False), [], [VS])

@@ -83,6 +83,33 @@ for dt in (torch.float16, torch.bfloat16):
                 worst = max(worst, err.max().item())
             bad += not ok
             print(f"{str(dt)[6:]:9s} varlen q{lq} k{lk_} causal={int(causal)}: max {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
+# the same batches over a PAGED K/V cache (pages of 64 .. 512 keys in a permuted pool, junk in the rows past a sequence's end):
+# the kernel's paged instances must reproduce the packed-K/V result of the varlen instances bit for bit
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import hip_path as hp
+for dt in (torch.float16, torch.bfloat16):
+    for lens in ([64], [1, 77, 300, 512, 1000], [2048, 1900], [513, 129, 640], [4096]):
+        for page in (64, 128, 512):
+            for causal in (False, True):
+                H, Hk, B, smax = 4, 2, len(lens), max(lens)
+                q = torch.randn(sum(lens), H, 128, device="cuda").to(dt)
+                kd = torch.randn(B, smax, Hk, 128, device="cuda").to(dt)
+                vd = torch.randn(B, smax, Hk, 128, device="cuda").to(dt)
+                cu = torch.tensor([0] + lens, device="cuda").cumsum(0).int()
+                kpk = torch.cat([kd[i, :n] for i, n in enumerate(lens)])
+                vpk = torch.cat([vd[i, :n] for i, n in enumerate(lens)])
+                want = mfa.flash_attn_varlen_func(q, kpk, vpk, cu, cu, smax, smax, causal=causal)
+                assert _lib.mfa_debug_last_route() & capi.MFA_ROUTE_PREFILL64
+                kp, vp, table = hp.make_paged(kd, vd, page, seed=3)
+                got = mfa.flash_attn_varlen_func(q, kp, vp, cu, cu, smax, smax, causal=causal, block_table=table)
+                route = _lib.mfa_debug_last_route()
+                torch.cuda.synchronize()
+                served = table.size(1) <= 64
+                assert bool(route & capi.MFA_ROUTE_PREFILL64) == served, (route, table.shape)
+                ok = bool(torch.equal(got, want)) if served else bool((got.float() - want.float()).abs().max() < 2e-2)
+                bad += not ok
+                print(f"{str(dt)[6:]:9s} paged q{lens} page {page} causal={int(causal)}: {'bit-equal' if served else 'general kernel'} {'ok' if ok else 'FAIL'}", flush=True)
 print("FAILURES:", bad, flush=True)
 if bad:
     sys.exit(1)
