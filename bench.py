@@ -12,7 +12,8 @@ A "step" is one pass of the hot path over one batch of synthetic input, already 
 Beside the contract's timed regions (outside them, and BEFORE them): "sweep" — the reference benchmark's prefill shape family
 (fp16 B=48 H=24 D=128, S = 256 .. 4096, causal and not), and "decode_sweep" — the reference README's MHA fp16
 decode shapes (B=24 H=24 Skv = 512 .. 8192) and BASELINE config 5 (paged), each over ROTATING cache copies so no
-launch finds its cache in the 256 MB Infinity Cache.  Every sweep entry carries two regimes: "cold" = the first 25
+launch finds its cache in the 256 MB Infinity Cache; "prefill_modes" — dense / packed varlen / paged K/V through the same
+head-dim-128 kernel at one shape.  Every sweep entry carries two regimes: "cold" = the first 25
 launches after an idle gap (clocks and power have not settled: a 25-launch run from idle measures the ramp, not the
 kernel) and "steady" = after about half a second of back-to-back launches.  Because the sweeps run first, the headline /
 decode / kvcache_packed regions start at settled clocks whatever --steps / --warmup are.
@@ -167,6 +168,32 @@ def prefill_sweep(mfa, dev):
     return out
 
 
+def prefill_modes(mfa, dev):
+    """The non-dense ways into the head-dim-128 prefill kernel at one shape (bf16, 16 sequences x 2048, H 24/8, causal): dense
+    (B,S,H,D), packed variable-length (cu_seqlens) and the same over a paged K/V cache (page 256, permuted block table); steady
+    TFLOP/s and the ratio to the dense launch"""
+    B, S, H, Hk, D, page = 16, 2048, 24, 8, 128, 256
+    flops = 4.0 * B * H * S * S * D * 0.5
+    q = torch.randn(B * S, H, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    kd, vd = (torch.randn(B, S, Hk, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(2))
+    cu = torch.arange(0, (B + 1) * S, S, device=dev, dtype=torch.int32)
+    nb = B * S // page
+    perm = torch.randperm(nb, generator=torch.Generator().manual_seed(0)).to(dev)
+    kp, vp = torch.empty(nb, page, Hk, D, device=dev, dtype=torch.bfloat16), torch.empty(nb, page, Hk, D, device=dev, dtype=torch.bfloat16)
+    kp[perm], vp[perm] = kd.view(nb, page, Hk, D), vd.view(nb, page, Hk, D)
+    table = perm.int().view(B, S // page).contiguous()
+    runs = (("dense", lambda: mfa.flash_attn_func(q.view(B, S, H, D), kd, vd, causal=True)),
+            ("varlen", lambda: mfa.flash_attn_varlen_func(q, kd.view(B * S, Hk, D), vd.view(B * S, Hk, D), cu, cu, S, S, causal=True)),
+            ("paged_page256", lambda: mfa.flash_attn_varlen_func(q, kp, vp, cu, cu, S, S, causal=True, block_table=table)))
+    out = {"workload": "bf16 16 x 2048 tokens, Hq24 Hkv8 D128, causal"}
+    for name, fn in runs:
+        _, steady = cold_and_steady(fn, steady_n=20, settle_s=0.5)
+        out[name] = {"ms": round(steady, 4), "tflops": round(flops / steady / 1e9, 1)}
+    for name in ("varlen", "paged_page256"):
+        out[name]["vs_dense"] = round(out["dense"]["ms"] / out[name]["ms"], 3)
+    return out
+
+
 def decode_sweep(mfa, dev):
     """README MHA fp16 decode shapes (B=24 H=24 D=128 Sq=1) and BASELINE config 5 (paged), over rotating cache copies"""
     out = []
@@ -248,6 +275,7 @@ def main():
     sweeps = {}
     if not args.no_sweep:
         sweeps["decode_sweep"] = decode_sweep(mfa, dev)
+        sweeps["prefill_modes"] = prefill_modes(mfa, dev)
         sweeps["sweep"] = prefill_sweep(mfa, dev)  # (last: the headline region follows the MFMA-heavy shapes directly)
         sweeps["regimes"] = ("cold = mean of the first 25 launches after a 0.25 s idle gap; steady = mean of 4-40 launches "
                              "after >= 0.3-0.5 s of back-to-back launches; HIP events on the launch stream; the headline, decode "
