@@ -300,7 +300,7 @@ def main():
         roof = {"bound": "mfma", "achieved": round(kern_tflops, 1), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4)}
     roof.update({"traffic": measured_traffic("prefill"), "traffic_source": "profiles/traffic.json (replayed)",
-                 "kernel": "prefill64_kernel<Half>", "kernel_ms": round(ev_ms, 4),
+                 "kernel": "prefill64_kernel<Half, dense>", "kernel_ms": round(ev_ms, 4),
                  "mfma_tflops": round(kern_tflops, 1), "mfma_frac": round(kern_tflops / PEAK_MFMA_TFLOPS, 4),
                  "hbm_gbps": round(kern_gbps, 1), "hbm_frac": round(kern_gbps / PEAK_HBM_GBPS, 4),
                  "algorithmic_flops": prefill_flops(c), "algorithmic_bytes": prefill_bytes(c)})

@@ -20,7 +20,8 @@ def counters(path):
     files = glob.glob(path)
     if not files:
         return d
-    for r in csv.DictReader(open(files[0])):
+    # (gpurun merges every call's output into the same tree: the newest file is this run's)
+    for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
         d[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return d
 
@@ -32,7 +33,7 @@ def short(name):
 def main(tag, name):
     src = os.path.join(ROOT, "gpurun_out", tag)
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+    stats = max(glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     rows = [r for r in csv.DictReader(open(stats)) if "mfa::" in r["Name"]]
     with open(os.path.join(ROOT, "profiles", f"{name}_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
