@@ -80,7 +80,7 @@ def strict_report(out, ref, name, must_pass=True, why=""):
         rec["note"] = why
     outdir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(outdir, exist_ok=True)
-    path = os.path.join(outdir, "parity_r03.json")
+    path = os.path.join(outdir, os.environ.get("MFA_PARITY_RECORD", "parity_r03.json"))  # (a forced-route child run keeps its own file)
     try:
         with open(path) as f:
             allrec = json.load(f)
