@@ -108,18 +108,30 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
         const int p8 = npairs >> 3, r8 = npairs & 7;
         const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
-        const int pair_count = p8 + (x < r8 ? 1 : 0);
+        // per-sequence lengths (varlen, per-batch cache lengths): a contiguous range of pairs per XCD would hand a long
+        // sequence's heads to ONE XCD (bf16 H24/8, one 8192-token sequence beside 31 of 256: 2.5 ms, one XCD doing the work of
+        // eight).  There the (batch, KV head) pairs are dealt round-robin -- XCD x takes x, x + 8, ... with their query heads
+        const int kv_mine = a.interleave_pairs ? (a.batch * a.kv_heads - x + 7) >> 3 : 0;
+        const int pair_count = a.interleave_pairs ? kv_mine * a.group : p8 + (x < r8 ? 1 : 0);
         const int gp = a.group_pairs;
         const int g = k / (gp * nmb), t = k - g * (gp * nmb);
         const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
         if (gsize <= 0) return;
         const int rank = t / gsize, pi = t - rank * gsize;
         if (rank >= nmb) return; // padding of a short group
-        const int bh = pair_begin + g * gp + pi;
         const int mblk = nmb - 1 - rank; // heaviest causal blocks first
-        hq = bh % a.heads;
-        b = bh / a.heads;
-        hk = hq / a.group;
+        if (a.interleave_pairs) {
+            const int pl = g * gp + pi, kvl = pl / a.group;
+            const int kv = x + 8 * kvl;
+            b = kv / a.kv_heads;
+            hk = kv - b * a.kv_heads;
+            hq = hk * a.group + (pl - kvl * a.group);
+        } else {
+            const int bh = pair_begin + g * gp + pi;
+            hq = bh % a.heads;
+            b = bh / a.heads;
+            hk = hq / a.group;
+        }
         m0 = mblk * BM;
     } else {
         // (batch, KV head) pair p runs on XCD p & 7 (workgroups bid, bid + 8, ... share one) with all its key splits and row
@@ -614,7 +626,8 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     const int knob_gp = g_knobs.group_pairs.load();
     a.group_pairs = knob_gp > 0 ? knob_gp : 4;
     // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
-    const int64_t per_xcd = (npairs + 7) / 8;
+    a.interleave_pairs = a.cu_q != nullptr || a.seqlens_k != nullptr; // (lengths differ by batch element: see the kernel)
+    const int64_t per_xcd = a.interleave_pairs ? (((int64_t)a.batch * a.kv_heads + 7) / 8) * a.group : (npairs + 7) / 8;
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
     const int64_t total = 8 * groups * a.group_pairs * a.num_m_blocks;
     if (total > 0x7fffffffLL) return -1;
@@ -699,7 +712,16 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream, bool* used_p
     // 1024..2048 0.477 / 0.505, 512..4096 0.774 / 0.902, 128..4096 log-uniform 1.21 / 1.61).
     const int p64_from = a.has_hi ? 512 : 384;
     bool p64_fits = a.seqlen_k >= p64_from;
-    if (a.cu_q) p64_fits = p64_fits && a.batch > 0 && a.seqlen_q >= p64_from && 10 * a.total_q >= 9 * (int64_t)a.batch * a.seqlen_q;
+    if (a.cu_q) {
+        const bool even = a.batch > 0 && 10 * a.total_q >= 9 * (int64_t)a.batch * a.seqlen_q;
+        a.p64_ragged = !even;
+        // ragged: the length-sorted schedule (at most 64 sequences of at most 64 row blocks) where long sequences carry the
+        // work -- a mean length of 512, or a longest sequence that outweighs the rest even if the rest were all 256 long
+        // (the general kernel is the faster one on sequences that short)
+        const int64_t rest = a.total_q - a.seqlen_q;
+        const bool long_heavy = a.total_q >= 512 * (int64_t)a.batch || (int64_t)a.seqlen_q * a.seqlen_q >= 256 * rest;
+        p64_fits = p64_fits && a.seqlen_q >= p64_from && (even || (a.batch <= 64 && a.seqlen_q <= 64 * 256 && long_heavy));
+    }
     if (env_p64 == 2 || (env_p64 == 1 && p64_fits)) {
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
         if (rc != -2) {

@@ -2,6 +2,8 @@
 golden fixtures, and size-independent properties at BASELINE sizes.  Mirrors what reference tests/test_mha.py,
 test_causal.py, test_gqa.py, test_arbitrary_seqlen.py, test_varlen.py and test_varlen_block_table.py cover (the
 last one value-checked here; upstream it only checks finiteness)."""
+import os
+
 import pytest
 import torch
 
@@ -151,9 +153,10 @@ def test_varlen_mixed_lengths(mfa, capi, oracle, dtype):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_varlen_even_batches_take_the_64_row_kernel(mfa, capi, oracle, dtype):
     """Head dim 128, mean length >= 0.9 max: the launcher hands the batch to prefill64_kernel's varlen instances (the route
-    query says so); a ragged batch of the same sizes stays on the general kernel.  Values against per-sequence SDPA-fp32."""
+    query says so); a batch whose work sits in short sequences stays on the general kernel.  Values against per-sequence
+    SDPA-fp32."""
     lib = capi.load()
-    for lens, want64 in (([512] * 6, True), ([640, 600, 620, 577], True), ([1024, 1000, 1024], True), ([640, 100, 620, 64], False)):
+    for lens, want64 in (([512] * 6, True), ([640, 600, 620, 577], True), ([1024, 1000, 1024], True), ([600] + [300] * 30, False)):
         tot = sum(lens)
         cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
         q, k, v = rnd(tot, 6, 128, dtype=dtype, seed=1), rnd(tot, 2, 128, dtype=dtype, seed=2), rnd(tot, 2, 128, dtype=dtype, seed=3)
@@ -162,8 +165,35 @@ def test_varlen_even_batches_take_the_64_row_kernel(mfa, capi, oracle, dtype):
             for route in hp.ROUTES:
                 out = hp.prefill(route, mfa, capi, q, k, v, causal, cu_q=cu, cu_k=cu, max_sq=max(lens), max_sk=max(lens))
                 bits = lib.mfa_debug_last_route()
-                assert bits & capi.MFA_ROUTE_PREFILL and bool(bits & capi.MFA_ROUTE_PREFILL64) == want64, (lens, route, bits)
+                assert bits & capi.MFA_ROUTE_PREFILL
+                if "MFA_PREFILL64" not in os.environ:
+                    assert bool(bits & capi.MFA_ROUTE_PREFILL64) == want64, (lens, route, bits)
                 assert_close(out, ref, p_rounded=True, what=f"varlen {lens} {route} causal={causal}")
+
+
+@pytest.mark.parametrize("H,Hk", [(8, 8), (6, 2)])
+def test_varlen_ragged_long_batches(mfa, capi, H, Hk):
+    """Ragged batches of long sequences, head dim 128 (one long sequence beside short ones; lengths spread over 100 .. 3000; an
+    empty sequence): the launcher's length-sorted schedule of the 64-row kernel where long sequences carry the work (the route
+    query says which kernel ran), the general kernel otherwise; values against per-sequence fp32 attention on the GPU."""
+    lib = capi.load()
+    g = torch.Generator().manual_seed(11)
+    for lens, want64 in (([4096] + [256] * 9, True), (torch.randint(100, 3001, (12,), generator=g).tolist(), True),
+                         ([2000, 0, 1500, 3, 700], True), ([1024] + [200] * 40, False)):
+        tot = sum(lens)
+        cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
+        q, k, v = rnd(tot, H, 128, dtype=torch.bfloat16, seed=1), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=2), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=3)
+        for causal in (False, True):
+            for route in hp.ROUTES:
+                out = hp.prefill(route, mfa, capi, q, k, v, causal, cu_q=cu, cu_k=cu, max_sq=max(lens), max_sk=max(lens))
+                if "MFA_PREFILL64" not in os.environ:  # (the launcher's own choice; a forced-route run skips the check)
+                    assert bool(lib.mfa_debug_last_route() & capi.MFA_ROUTE_PREFILL64) == want64, (lens[:4], route)
+                for i, n in enumerate(lens):
+                    if n == 0:
+                        continue
+                    s0 = int(cu[i])
+                    ref = hp.sdpa_gpu(q[s0:s0 + n][None], k[s0:s0 + n][None], v[s0:s0 + n][None], causal)[0]
+                    assert_close(out[s0:s0 + n], ref, p_rounded=True, what=f"ragged {lens[:4]} seq {i} {route} causal={causal}")
 
 
 def test_varlen_different_q_and_k_lengths(mfa, capi, oracle):
