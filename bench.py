@@ -191,6 +191,15 @@ def prefill_modes(mfa, dev):
         out[name] = {"ms": round(steady, 4), "tflops": round(flops / steady / 1e9, 1)}
     for name in ("varlen", "paged_page256"):
         out[name]["vs_dense"] = round(out["dense"]["ms"] / out[name]["ms"], 3)
+    # a ragged batch: 16 sequences of 512 .. 4096 tokens (seeded), packed varlen, causal
+    lens = torch.randint(512, 4097, (16,), generator=torch.Generator().manual_seed(1)).tolist()
+    tot = sum(lens)
+    qr = torch.randn(tot, H, D, device=dev, dtype=torch.float32).to(torch.bfloat16)
+    kr, vr = (torch.randn(tot, Hk, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(2))
+    cur = torch.tensor([0] + lens, device=dev).cumsum(0).int()
+    _, steady = cold_and_steady(lambda: mfa.flash_attn_varlen_func(qr, kr, vr, cur, cur, max(lens), max(lens), causal=True), steady_n=20, settle_s=0.5)
+    out["varlen_ragged"] = {"workload": f"bf16 16 sequences of 512 .. 4096 tokens ({tot} in all), Hq24 Hkv8 D128, causal", "ms": round(steady, 4),
+                            "tflops": round(sum(4.0 * H * n * n * D * 0.5 for n in lens) / steady / 1e9, 1)}
     return out
 
 
