@@ -81,6 +81,15 @@ for dt in (torch.float16, torch.bfloat16):
                 tol = 1e-3 + (1e-3 + (2 ** -11 if dt == torch.float16 else 2 ** -8)) * r.abs() + (3e-3 if dt == torch.bfloat16 else 0)
                 ok = ok and bool((err <= tol).all()) and bool((li - torch.logsumexp(sc, -1)).abs().max() < 2e-3)
                 worst = max(worst, err.max().item())
+            # a sequence's rows do not depend on what else is in the batch or on the schedule that dealt out its row blocks:
+            # each sequence once more as a batch of one, bit for bit
+            for i in range(len(lq)):
+                if lq[i] == 0 or lk_[i] == 0:
+                    continue
+                q0, k0 = int(cq[i]), int(ck[i])
+                c1q, c1k = torch.tensor([0, lq[i]], device="cuda").int(), torch.tensor([0, lk_[i]], device="cuda").int()
+                alone = mfa.flash_attn_varlen_func(q[q0:q0 + lq[i]], k[k0:k0 + lk_[i]], v[k0:k0 + lk_[i]], c1q, c1k, lq[i], lk_[i], causal=causal)
+                ok = ok and bool(torch.equal(alone, o[q0:q0 + lq[i]]))
             bad += not ok
             print(f"{str(dt)[6:]:9s} varlen q{lq} k{lk_} causal={int(causal)}: max {worst:.2e} {'ok' if ok else 'FAIL'}", flush=True)
 # the same batches over a PAGED K/V cache (pages of 64 .. 512 keys in a permuted pool, junk in the rows past a sequence's end):
