@@ -723,6 +723,7 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream, bool* used_p
         p64_fits = p64_fits && a.seqlen_q >= p64_from && (even || (a.batch <= 64 && a.seqlen_q <= 64 * 256 && long_heavy));
     }
     if (env_p64 == 2 || (env_p64 == 1 && p64_fits)) {
+        a.p64_forced = env_p64 == 2;
         const int rc = launch_prefill64(a, p.is_bf16 != 0, stream);
         if (rc != -2) {
             if (used_prefill64) *used_prefill64 = rc == 0;

@@ -156,10 +156,12 @@ def test_varlen_even_batches_take_the_64_row_kernel(mfa, capi, oracle, dtype):
     query says so); a batch whose work sits in short sequences stays on the general kernel.  Values against per-sequence
     SDPA-fp32."""
     lib = capi.load()
-    for lens, want64 in (([512] * 6, True), ([640, 600, 620, 577], True), ([1024, 1000, 1024], True), ([600] + [300] * 30, False)):
+    # (24 heads: 256-row work items for more than half the CUs, below which the launcher keeps the general kernel -- the last case)
+    for lens, H, want64 in (([512] * 6, 24, True), ([640, 600, 620, 577, 610], 24, True), ([1024, 1000, 1024], 24, True),
+                            ([600] + [300] * 30, 24, False), ([1024, 1000, 1024], 6, False)):
         tot = sum(lens)
         cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
-        q, k, v = rnd(tot, 6, 128, dtype=dtype, seed=1), rnd(tot, 2, 128, dtype=dtype, seed=2), rnd(tot, 2, 128, dtype=dtype, seed=3)
+        q, k, v = rnd(tot, H, 128, dtype=dtype, seed=1), rnd(tot, H // 3, 128, dtype=dtype, seed=2), rnd(tot, H // 3, 128, dtype=dtype, seed=3)
         for causal in (False, True):
             ref = oracle.sdpa_varlen(q.cpu(), k.cpu(), v.cpu(), cu.cpu(), cu.cpu(), causal)
             for route in hp.ROUTES:
@@ -171,7 +173,7 @@ def test_varlen_even_batches_take_the_64_row_kernel(mfa, capi, oracle, dtype):
                 assert_close(out, ref, p_rounded=True, what=f"varlen {lens} {route} causal={causal}")
 
 
-@pytest.mark.parametrize("H,Hk", [(8, 8), (6, 2)])
+@pytest.mark.parametrize("H,Hk", [(16, 16), (18, 6)])
 def test_varlen_ragged_long_batches(mfa, capi, H, Hk):
     """Ragged batches of long sequences, head dim 128 (one long sequence beside short ones; lengths spread over 100 .. 3000; an
     empty sequence): the launcher's length-sorted schedule of the 64-row kernel where long sequences carry the work (the route
@@ -179,7 +181,7 @@ def test_varlen_ragged_long_batches(mfa, capi, H, Hk):
     lib = capi.load()
     g = torch.Generator().manual_seed(11)
     for lens, want64 in (([4096] + [256] * 9, True), (torch.randint(100, 3001, (12,), generator=g).tolist(), True),
-                         ([2000, 0, 1500, 3, 700], True), ([1024] + [200] * 40, False)):
+                         ([2000, 0, 1500, 3, 700], True), ([1024] + [200] * 40, False), ([600, 400], False)):
         tot = sum(lens)
         cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
         q, k, v = rnd(tot, H, 128, dtype=torch.bfloat16, seed=1), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=2), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=3)
