@@ -110,9 +110,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int pair_begin = x < r8 ? x * (p8 + 1) : r8 * (p8 + 1) + (x - r8) * p8;
         // per-sequence lengths (varlen, per-batch cache lengths): a contiguous range of pairs per XCD would hand a long
         // sequence's heads to ONE XCD (bf16 H24/8, one 8192-token sequence beside 31 of 256: 2.5 ms, one XCD doing the work of
-        // eight).  There the (batch, KV head) pairs are dealt round-robin -- XCD x takes x, x + 8, ... with their query heads
-        const int kv_mine = a.interleave_pairs ? (a.batch * a.kv_heads - x + 7) >> 3 : 0;
-        const int pair_count = a.interleave_pairs ? kv_mine * a.group : p8 + (x < r8 ? 1 : 0);
+        // eight).  There the pairs are dealt round-robin: (batch, KV head) pairs with their query heads when there are at least two
+        // per XCD (interleave_pairs == 2: XCD x takes x, x + 8, ...; a KV head's K/V stays in one L2), (batch, head) pairs
+        // otherwise (== 1)
+        const int dealt = a.interleave_pairs == 2 ? a.batch * a.kv_heads : npairs;
+        const int mine = (dealt - x + 7) >> 3;
+        const int pair_count = a.interleave_pairs == 2 ? mine * a.group : a.interleave_pairs == 1 ? mine : p8 + (x < r8 ? 1 : 0);
         const int gp = a.group_pairs;
         const int g = k / (gp * nmb), t = k - g * (gp * nmb);
         const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
@@ -120,12 +123,17 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int rank = t / gsize, pi = t - rank * gsize;
         if (rank >= nmb) return; // padding of a short group
         const int mblk = nmb - 1 - rank; // heaviest causal blocks first
-        if (a.interleave_pairs) {
+        if (a.interleave_pairs == 2) {
             const int pl = g * gp + pi, kvl = pl / a.group;
             const int kv = x + 8 * kvl;
             b = kv / a.kv_heads;
             hk = kv - b * a.kv_heads;
             hq = hk * a.group + (pl - kvl * a.group);
+        } else if (a.interleave_pairs == 1) {
+            const int bh = x + 8 * (g * gp + pi);
+            hq = bh % a.heads;
+            b = bh / a.heads;
+            hk = hq / a.group;
         } else {
             const int bh = pair_begin + g * gp + pi;
             hq = bh % a.heads;
@@ -626,8 +634,9 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     const int knob_gp = g_knobs.group_pairs.load();
     a.group_pairs = knob_gp > 0 ? knob_gp : 4;
     // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
-    a.interleave_pairs = a.cu_q != nullptr || a.seqlens_k != nullptr; // (lengths differ by batch element: see the kernel)
-    const int64_t per_xcd = a.interleave_pairs ? (((int64_t)a.batch * a.kv_heads + 7) / 8) * a.group : (npairs + 7) / 8;
+    // (lengths differ by batch element: pairs dealt round-robin over the XCDs, see the kernel)
+    a.interleave_pairs = !(a.cu_q || a.seqlens_k) ? 0 : (int64_t)a.batch * a.kv_heads >= 16 ? 2 : 1;
+    const int64_t per_xcd = a.interleave_pairs == 2 ? (((int64_t)a.batch * a.kv_heads + 7) / 8) * a.group : (npairs + 7) / 8;
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
     const int64_t total = 8 * groups * a.group_pairs * a.num_m_blocks;
     if (total > 0x7fffffffLL) return -1;
