@@ -117,13 +117,26 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int mine = (dealt - x + 7) >> 3;
         const int pair_count = a.interleave_pairs == 2 ? mine * a.group : a.interleave_pairs == 1 ? mine : p8 + (x < r8 ? 1 : 0);
         const int gp = a.group_pairs;
-        const int g = k / (gp * nmb), t = k - g * (gp * nmb);
+        int g = k / (gp * nmb);
+        const int t = k - g * (gp * nmb);
         const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
-        if (gsize <= 0) return;
-        const int rank = t / gsize, pi = t - rank * gsize;
+        int rank, pi;
+        if (a.interleave_pairs == 3) { // fewer than 8 pairs: no XCD of its own for a pair; query-block-major over all of them
+            rank = blockIdx.x / npairs;
+            pi = blockIdx.x - rank * npairs;
+            g = 0;
+        } else {
+            if (gsize <= 0) return;
+            rank = t / gsize;
+            pi = t - rank * gsize;
+        }
         if (rank >= nmb) return; // padding of a short group
         const int mblk = nmb - 1 - rank; // heaviest causal blocks first
-        if (a.interleave_pairs == 2) {
+        if (a.interleave_pairs == 3) {
+            hq = pi % a.heads;
+            b = pi / a.heads;
+            hk = hq / a.group;
+        } else if (a.interleave_pairs == 2) {
             const int pl = g * gp + pi, kvl = pl / a.group;
             const int kv = x + 8 * kvl;
             b = kv / a.kv_heads;
@@ -635,10 +648,12 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     a.group_pairs = knob_gp > 0 ? knob_gp : 4;
     // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
     // (lengths differ by batch element: pairs dealt round-robin over the XCDs, see the kernel)
-    a.interleave_pairs = !(a.cu_q || a.seqlens_k) ? 0 : (int64_t)a.batch * a.kv_heads >= 16 ? 2 : 1;
+    // fewer than 8 pairs (one long prompt on a tensor-parallel shard's few heads): an XCD per pair would leave XCDs idle; the
+    // row blocks of all pairs go out in plain order instead (3)
+    a.interleave_pairs = npairs < 8 ? 3 : !(a.cu_q || a.seqlens_k) ? 0 : (int64_t)a.batch * a.kv_heads >= 16 ? 2 : 1;
     const int64_t per_xcd = a.interleave_pairs == 2 ? (((int64_t)a.batch * a.kv_heads + 7) / 8) * a.group : (npairs + 7) / 8;
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
-    const int64_t total = 8 * groups * a.group_pairs * a.num_m_blocks;
+    const int64_t total = a.interleave_pairs == 3 ? npairs * a.num_m_blocks : 8 * groups * a.group_pairs * a.num_m_blocks;
     if (total > 0x7fffffffLL) return -1;
     auto kern = prefill_fwd_kernel<T, D, NW, PG>;
     if (smem > 64 * 1024 &&

@@ -27,7 +27,7 @@ struct PrefillArgs {
     int32_t num_m_blocks;
     int32_t group_pairs; // (batch, head) pairs per scheduling group
     int32_t interleave_pairs; // general kernel: pairs dealt round-robin over the XCDs instead of in contiguous ranges: 1 (batch,
-                              // head) pairs, 2 (batch, KV head) pairs with their query heads
+                              // head) pairs, 2 (batch, KV head) pairs with their query heads, 3 fewer than 8 pairs: plain order
     int32_t p64_forced;  // MFA_PREFILL64=2 (tests, probes): the 64-row kernel for everything it serves, whatever the launch size
     int32_t p64_ragged;  // 64-row kernel, varlen: the launcher found the batch ragged (mean length < 0.9 max): length-sorted schedule
     int32_t is_causal;
