@@ -305,14 +305,14 @@ static int64_t decode_head_chunks(int g) { // (mfa_decode.hip launch_decode: gro
 size_t mfa_kvcache_counter_count(const mfa_forward_params* p) {
     if (!p || p->num_splits <= 1 || p->kv_heads <= 0 || p->heads % p->kv_heads != 0 || p->seqlen_q < 1) return 0;
     const int g = p->heads / p->kv_heads;
-    int64_t n = 0;
+    int64_t n = 0, units = 0;
     mfa_forward_params one = *p;
     switch (kvcache_route(p)) {
-    case kKvDecode: n = (int64_t)p->batch * p->kv_heads * decode_head_chunks(g); one.seqlen_q = 1; break;
-    case kKvPacked: n = (int64_t)p->batch * p->kv_heads * (((int64_t)p->seqlen_q * g + 127) / 128); break;
+    case kKvDecode: units = n = (int64_t)p->batch * p->kv_heads * decode_head_chunks(g); one.seqlen_q = 1; break;
+    case kKvPacked: units = (int64_t)p->batch * p->kv_heads; n = units * (((int64_t)p->seqlen_q * g + 127) / 128); break;
     default: return 0;
     }
-    if (n > MFA_SPLIT_COUNTERS_MAX || !mfa::fused_merge_pays(n * p->num_splits, mfa::partial_bytes(one))) return 0;
+    if (n > MFA_SPLIT_COUNTERS_MAX || !mfa::fused_merge_pays(units, n * p->num_splits, mfa::partial_bytes(one))) return 0;
     return (size_t)n;
 }
 

@@ -89,13 +89,22 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     // which the in-kernel merge below relies on -- while neighbouring rows (the KV heads of one batch element) sit on different
     // XCDs, each reading its 256-byte piece of the same K/V rows: unsplit this is the plain order bid = row.  (Round 2 gave XCD
     // x a CONTIGUOUS range of rows: 3 % slower on config 3, 5 % on the README MHA shape, same box, profiles/r03a_ab_*.)
+    // Fewer than 8 rows with key splits (one or two long sequences on a tensor-parallel shard's one or two KV heads): a row's
+    // splits on one XCD would leave the other XCDs idle -- they go out in plain order over all of them, and the merge is the
+    // separate launch (launch_decode hands over no counters then).
     int split, row;
     {
-        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        const int ri = k / a.num_splits;
-        split = k - ri * a.num_splits;
-        row = 8 * ri + x;
-        if (row >= a.batch * a.kv_heads * a.nchunks) return;
+        const int nrows = a.batch * a.kv_heads * a.nchunks;
+        if (nrows < 8 && a.num_splits > 1) {
+            split = blockIdx.x / nrows;
+            row = blockIdx.x - split * nrows;
+        } else {
+            const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+            const int ri = k / a.num_splits;
+            split = k - ri * a.num_splits;
+            row = 8 * ri + x;
+            if (row >= nrows) return;
+        }
     }
     const int b = row / (a.kv_heads * a.nchunks);
     const int hk = (row - b * a.kv_heads * a.nchunks) / a.nchunks;
@@ -367,7 +376,7 @@ __global__ __launch_bounds__(64 * kCombineRows) void decode_combine_kernel(const
 template <typename T, int LPR, int GT>
 static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
     const int64_t R = (int64_t)a.batch * a.kv_heads * a.nchunks;
-    dim3 grid((unsigned)(8 * ((R >> 3) + ((R & 7) ? 1 : 0)) * a.num_splits));
+    dim3 grid((unsigned)(R < 8 && a.num_splits > 1 ? R * a.num_splits : 8 * ((R >> 3) + ((R & 7) ? 1 : 0)) * a.num_splits));
     const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
     if (!a.block_table)
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kDense>), grid, dim3(kDecodeThreads), smem, stream, a);
@@ -445,7 +454,7 @@ int launch_decode(const mfa_forward_params& p, hipStream_t stream, bool* merged_
         mfa_forward_params one = p; // (the partials of flash decoding: one query position)
         one.seqlen_q = 1;
         one.num_splits = a.num_splits;
-        a.split_ctr = pick_split_counters(p, (size_t)rows, rows * a.num_splits, partial_bytes(one));
+        a.split_ctr = pick_split_counters(p, (size_t)rows, rows, rows * a.num_splits, partial_bytes(one));
     }
     if (merged_in_kernel) *merged_in_kernel = a.split_ctr != nullptr;
     return p.is_bf16 ? launch_decode_d<BFloat>(a, gt, stream) : launch_decode_d<Half>(a, gt, stream);

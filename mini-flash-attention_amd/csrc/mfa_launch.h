@@ -27,8 +27,10 @@ int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream);
 // and may run in the split kernel -- n counters needed, `workgroups` in the split launch, `partial_bytes` of fp32
 // partials -- else null (the launcher then runs decode_combine_kernel behind the split kernel).
 int xcd_premise_probe(int device);
-bool fused_merge_pays(int64_t workgroups, int64_t pbytes);
-int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t workgroups, int64_t pbytes);
+// units: the (batch, KV head[, head chunk]) rows the launch deals over the XCDs -- fewer than 8 of them and the splits of a row
+// are spread over ALL XCDs instead (one row's splits on one XCD would leave the others idle), so the merge is its own launch
+bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes);
+int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t units, int64_t workgroups, int64_t pbytes);
 #ifdef MFA_DEV_DECODE_AB // (developer A/B builds: no size gate, tools/ab_decode_map.py measures both sides of it)
 constexpr int64_t kFusedMergeMaxWorkgroups = 1 << 30;
 constexpr int64_t kFusedMergeMaxPartialBytes = 1ll << 40;

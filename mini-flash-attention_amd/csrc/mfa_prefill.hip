@@ -160,8 +160,12 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int npairs = a.batch * a.kv_heads;
         const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
         const int per_pair = a.num_splits * a.mq_row_blocks;
-        const int pi = k / per_pair, t = k - pi * per_pair;
-        const int bk = 8 * pi + x;
+        int pi = k / per_pair, t = k - pi * per_pair;
+        int bk = 8 * pi + x;
+        if (npairs < 8 && a.num_splits > 1) { // (few pairs: their splits and row blocks in plain order over all XCDs, see mfa_decode.hip)
+            t = blockIdx.x / npairs;
+            bk = blockIdx.x - t * npairs;
+        }
         if (bk >= npairs) return;
         b = bk / a.kv_heads;
         hk = bk - b * a.kv_heads;
@@ -768,7 +772,7 @@ static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
     a.mq_row_blocks = (a.mq_rows + BM - 1) / BM;
     const int64_t npairs = (int64_t)a.batch * a.kv_heads;
     if (npairs <= 0 || a.mq_rows <= 0) return 0;
-    const int64_t total = 8 * ((npairs + 7) / 8) * a.num_splits * a.mq_row_blocks;
+    const int64_t total = (npairs < 8 && a.num_splits > 1 ? npairs : 8 * ((npairs + 7) / 8)) * a.num_splits * a.mq_row_blocks;
     if (total > 0x7fffffffLL) return -1;
     auto kern = prefill_fwd_kernel<T, D, NW, PG, true, false>;
     const int env_nt = g_knobs.mq_stream.load();
@@ -853,22 +857,22 @@ int xcd_premise_probe(int dev) {
 // `partial_bytes` of fp32 partials, and with which counters: the caller's (mfa_forward_params::split_counters, zeroed, at
 // least n entries), provided mfa_init() found the XCD premise to hold on this device.  Otherwise null: the caller of this
 // function launches decode_combine_kernel behind the split kernel.
-bool fused_merge_pays(int64_t workgroups, int64_t pbytes) {
+bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes) {
     // Measured (tools/ab_decode_map.py, one box, interleaved rounds; profiles/r03a_ab_decode_map_and_merge.txt): the
     // in-kernel merge saves 1.0-1.3 us of 15-30 us on launches of at most one round of workgroups (256: B4 Skv8192, B8
     // Skv4096, B16 Skv2048; 512 on the packed kernel: BASELINE config 5, 50.9 -> 49.2 us) and LOSES where later rounds
     // of streaming workgroups queue behind the winners' invalidate and re-read: 768 workgroups +1.0 us (config 3 forced
     // to 4 splits), 1 152 +6.6 us of 32 (README MHA B24 H24 Skv512), 1 536 +0.9 us (G=8, Skv8192).
-    return workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes;
+    return units >= 8 && workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes;
 }
-int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t workgroups, int64_t pbytes) {
+int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t units, int64_t workgroups, int64_t pbytes) {
 #ifdef MFA_DEV_DECODE_AB // developer A/B builds: read per launch; =2: no size gate
     const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
 #else
     static const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
 #endif
     if (!env || !p.split_counters || (size_t)(p.split_counters_len < 0 ? 0 : p.split_counters_len) < n) return nullptr;
-    if (env != 2 && !fused_merge_pays(workgroups, pbytes)) return nullptr;
+    if (units < 8 || (env != 2 && !fused_merge_pays(units, workgroups, pbytes))) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || g_xcd_state[dev].load() != 1) return nullptr;
     return p.split_counters;
@@ -884,7 +888,7 @@ int launch_kvcache_packed(const mfa_forward_params& p, hipStream_t stream, bool*
     if (a.num_splits > 1) {
         const int64_t row_blocks = ((int64_t)a.seqlen_q * a.group + 127) / 128;
         const int64_t n = (int64_t)a.batch * a.kv_heads * row_blocks;
-        a.split_ctr = pick_split_counters(p, (size_t)n, n * a.num_splits, partial_bytes(p));
+        a.split_ctr = pick_split_counters(p, (size_t)n, (int64_t)a.batch * a.kv_heads, n * a.num_splits, partial_bytes(p));
     }
     const int rc = p.is_bf16 ? launch_mq_d<BFloat>(a, stream) : launch_mq_d<Half>(a, stream);
     if (rc) return rc;

@@ -98,10 +98,10 @@ def test_graph_capture_with_and_without_split_counters(mfa, capi):
     merges through decode_combine_kernel.  (b) On a stream whose buffer exists, the captured launch merges in the kernel
     and keeps a pointer that stays valid: after unrelated, larger split launches the replay still equals the eager call."""
     lib = capi.load()
-    B, H, Hk, D = 2, 8, 2, 128
+    B, H, Hk, D = 4, 8, 2, 128  # (8 (batch, KV head) rows: with fewer the splits go out over all XCDs and never merge in the kernel)
     qd = rnd(B, 1, H, D, dtype=torch.bfloat16, seed=4)
     kc, vc = rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=5), rnd(B, 2048, Hk, D, dtype=torch.bfloat16, seed=6)
-    lens = torch.tensor([2000, 777], dtype=torch.int32, device=DEV)
+    lens = torch.tensor([2000, 777, 1500, 64], dtype=torch.int32, device=DEV)
     call = lambda: mfa.flash_attn_with_kvcache(qd, kc, vc, cache_seqlens=lens, num_splits=4)
     eager = call()
     assert lib.mfa_debug_last_route() == capi.MFA_ROUTE_DECODE | capi.MFA_ROUTE_FUSED_MERGE
