@@ -181,7 +181,8 @@ int mfa_init(int device);
 
 /* int32 entries the kv-cache entry would use from p->split_counters for this problem (p->num_splits resolved by
  * mfa_kvcache_plan): 0 when the launch is unsplit or when the library keeps the merge as its own launch for this size
- * (large launches, where the merge launch is cheaper than the winners' cache invalidations).  Never more than
+ * (large launches, where the merge launch is cheaper than the winners' cache invalidations; small launches whose row count is
+ * no multiple of 8, whose splits are spread over all XCDs).  Never more than
  * MFA_SPLIT_COUNTERS_MAX, so a caller may allocate that many once. */
 size_t mfa_kvcache_counter_count(const mfa_forward_params* p);
 #define MFA_SPLIT_COUNTERS_MAX 65536

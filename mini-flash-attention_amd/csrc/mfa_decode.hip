@@ -89,13 +89,14 @@ __global__ __launch_bounds__(kDecodeThreads) void decode_split_kv_kernel(const D
     // which the in-kernel merge below relies on -- while neighbouring rows (the KV heads of one batch element) sit on different
     // XCDs, each reading its 256-byte piece of the same K/V rows: unsplit this is the plain order bid = row.  (Round 2 gave XCD
     // x a CONTIGUOUS range of rows: 3 % slower on config 3, 5 % on the README MHA shape, same box, profiles/r03a_ab_*.)
-    // Fewer than 8 rows with key splits (one or two long sequences on a tensor-parallel shard's one or two KV heads): a row's
-    // splits on one XCD would leave the other XCDs idle -- they go out in plain order over all of them, and the merge is the
-    // separate launch (launch_decode hands over no counters then).
+    // A small row count that is no multiple of 8 (fewer than 8: one or two long sequences on a tensor-parallel shard's one or two
+    // KV heads) with key splits: one XCD per row would load the XCDs unevenly or leave some idle (spread_splits, mfa_launch.h) --
+    // the splits go out in plain order over all of them, and the merge is the separate launch (launch_decode hands over no
+    // counters then).
     int split, row;
     {
         const int nrows = a.batch * a.kv_heads * a.nchunks;
-        if (nrows < 8 && a.num_splits > 1) {
+        if (spread_splits(nrows, a.num_splits)) {
             split = blockIdx.x / nrows;
             row = blockIdx.x - split * nrows;
         } else {
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(64 * kCombineRows) void decode_combine_kernel(const
 template <typename T, int LPR, int GT>
 static int launch_decode_t(const DecodeArgs& a, hipStream_t stream) {
     const int64_t R = (int64_t)a.batch * a.kv_heads * a.nchunks;
-    dim3 grid((unsigned)(R < 8 && a.num_splits > 1 ? R * a.num_splits : 8 * ((R >> 3) + ((R & 7) ? 1 : 0)) * a.num_splits));
+    dim3 grid((unsigned)(spread_splits(R, a.num_splits) ? R * a.num_splits : 8 * ((R >> 3) + ((R & 7) ? 1 : 0)) * a.num_splits));
     const size_t smem = sizeof(float) * kDecodeWaves * GT * (2 + LPR * 8);
     if (!a.block_table)
         hipLaunchKernelGGL((decode_split_kv_kernel<T, LPR, GT, kDense>), grid, dim3(kDecodeThreads), smem, stream, a);

@@ -27,8 +27,12 @@ int launch_decode_combine(const mfa_forward_params& p, hipStream_t stream);
 // and may run in the split kernel -- n counters needed, `workgroups` in the split launch, `partial_bytes` of fp32
 // partials -- else null (the launcher then runs decode_combine_kernel behind the split kernel).
 int xcd_premise_probe(int device);
-// units: the (batch, KV head[, head chunk]) rows the launch deals over the XCDs -- fewer than 8 of them and the splits of a row
-// are spread over ALL XCDs instead (one row's splits on one XCD would leave the others idle), so the merge is its own launch
+// units: the (batch, KV head[, head chunk]) rows the launch deals over the XCDs.  A row's key splits share an XCD (the in-kernel
+// merge needs that), rows r, r + 8, ... share one: with a row count that is no multiple of 8 some XCDs carry one row more than
+// others -- 9 rows: XCD 0 two, the rest one; bf16 Hq4 Hkv1 Skv32768, 9 sequences 50 us where 8 take 30, 17 take 84 where 16 take
+// 48 -- and with fewer than 8 rows some carry none.  For such small launches the splits go out in plain order over all XCDs and
+// the merge is its own launch.  (Kernels and launchers ask this one function.)
+__host__ __device__ inline bool spread_splits(int64_t units, int splits) { return splits > 1 && units < 64 && (units & 7) != 0; }
 bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes);
 int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t units, int64_t workgroups, int64_t pbytes);
 #ifdef MFA_DEV_DECODE_AB // (developer A/B builds: no size gate, tools/ab_decode_map.py measures both sides of it)

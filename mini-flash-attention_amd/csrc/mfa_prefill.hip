@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int per_pair = a.num_splits * a.mq_row_blocks;
         int pi = k / per_pair, t = k - pi * per_pair;
         int bk = 8 * pi + x;
-        if (npairs < 8 && a.num_splits > 1) { // (few pairs: their splits and row blocks in plain order over all XCDs, see mfa_decode.hip)
+        if (spread_splits(npairs, a.num_splits)) { // (few pairs: their splits and row blocks in plain order over all XCDs, mfa_launch.h)
             t = blockIdx.x / npairs;
             bk = blockIdx.x - t * npairs;
         }
@@ -772,7 +772,7 @@ static int launch_mq_p(PrefillArgs& a, hipStream_t stream) {
     a.mq_row_blocks = (a.mq_rows + BM - 1) / BM;
     const int64_t npairs = (int64_t)a.batch * a.kv_heads;
     if (npairs <= 0 || a.mq_rows <= 0) return 0;
-    const int64_t total = (npairs < 8 && a.num_splits > 1 ? npairs : 8 * ((npairs + 7) / 8)) * a.num_splits * a.mq_row_blocks;
+    const int64_t total = (spread_splits(npairs, a.num_splits) ? npairs : 8 * ((npairs + 7) / 8)) * a.num_splits * a.mq_row_blocks;
     if (total > 0x7fffffffLL) return -1;
     auto kern = prefill_fwd_kernel<T, D, NW, PG, true, false>;
     const int env_nt = g_knobs.mq_stream.load();
@@ -863,7 +863,7 @@ bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes) {
     // Skv4096, B16 Skv2048; 512 on the packed kernel: BASELINE config 5, 50.9 -> 49.2 us) and LOSES where later rounds
     // of streaming workgroups queue behind the winners' invalidate and re-read: 768 workgroups +1.0 us (config 3 forced
     // to 4 splits), 1 152 +6.6 us of 32 (README MHA B24 H24 Skv512), 1 536 +0.9 us (G=8, Skv8192).
-    return units >= 8 && workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes;
+    return !spread_splits(units, 2) && workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes;
 }
 int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t units, int64_t workgroups, int64_t pbytes) {
 #ifdef MFA_DEV_DECODE_AB // developer A/B builds: read per launch; =2: no size gate
@@ -872,7 +872,7 @@ int32_t* pick_split_counters(const mfa_forward_params& p, size_t n, int64_t unit
     static const int env = [] { const char* e = getenv("MFA_FUSED_COMBINE"); return e ? atoi(e) : 1; }();
 #endif
     if (!env || !p.split_counters || (size_t)(p.split_counters_len < 0 ? 0 : p.split_counters_len) < n) return nullptr;
-    if (units < 8 || (env != 2 && !fused_merge_pays(units, workgroups, pbytes))) return nullptr;
+    if (spread_splits(units, 2) || (env != 2 && !fused_merge_pays(units, workgroups, pbytes))) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || g_xcd_state[dev].load() != 1) return nullptr;
     return p.split_counters;

@@ -16,7 +16,8 @@ out = {}
 routes = []
 g = torch.Generator().manual_seed(7)
 # (B, Sq, Hq, Hk, Sk, D, page or 0, splits)
-# (cases 2 and 7 have fewer than 8 (batch, KV head) rows: their splits are spread over all XCDs and merged by the combine launch)
+# (cases 2, 4 and 7 have a small (batch, KV head) row count that is no multiple of 8: their splits are spread over all XCDs and
+# merged by the combine launch)
 cases = [(4, 1, 6, 2, 2500, 128, 0, 5), (2, 1, 8, 8, 4100, 64, 0, 7), (4, 1, 4, 1, 1500, 128, 0, 0), (1, 1, 24, 8, 9000, 128, 0, 0),
          (5, 1, 16, 2, 3000, 128, 0, 6), (4, 3, 16, 2, 2000, 128, 0, 4), (3, 1, 24, 8, 2048, 128, 256, 4), (2, 5, 8, 1, 1300, 64, 64, 3),
          (2, 1, 32, 4, 5000, 256, 0, 9), (6, 2, 12, 4, 777, 96, 0, 2)]

@@ -15,7 +15,7 @@ int launch_kvcache_packed(const mfa_forward_params&, hipStream_t, bool* f) { ++m
 int launch_decode_combine(const mfa_forward_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
 int launch_kvcache_append(const mfa_kvcache_append_params&, hipStream_t) { ++mfa_test_launch_count; return 0; }
 int xcd_premise_probe(int) { return 0; }
-bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes) { return units >= 8 && workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes; }
+bool fused_merge_pays(int64_t units, int64_t workgroups, int64_t pbytes) { return !spread_splits(units, 2) && workgroups <= kFusedMergeMaxWorkgroups && pbytes <= kFusedMergeMaxPartialBytes; }
 } // namespace mfa
 
 extern "C" {

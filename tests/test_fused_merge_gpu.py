@@ -27,9 +27,10 @@ def test_in_kernel_merge_equals_combine_launch(tmp_path):
         routes = [int(x) for x in r.stdout.split("routes", 1)[1].split("units")[0].split()]
         units = [int(x) for x in r.stdout.split("units", 1)[1].split()]
         split = [(x, u) for x, u in zip(routes, units) if x & (8 | 16)]  # MFA_ROUTE_COMBINE_LAUNCH | MFA_ROUTE_FUSED_MERGE
-        assert len(routes) == 10 and len(split) >= 8 and sum(u < 8 for _, u in split) >= 1, (routes, units)
-        # in-kernel merge wherever it is allowed: not with fewer than 8 rows (their splits go out over all XCDs)
-        assert all(x & (8 | 16) == (16 if flag == "1" and u >= 8 else 8) for x, u in split), (flag, routes, units)
+        spread = lambda u: u < 64 and u % 8 != 0  # (spread_splits, csrc/mfa_launch.h: such launches' splits go out over all XCDs)
+        assert len(routes) == 10 and len(split) >= 8 and 1 <= sum(spread(u) for _, u in split) <= 4, (routes, units)
+        # in-kernel merge wherever it is allowed
+        assert all(x & (8 | 16) == (16 if flag == "1" and not spread(u) else 8) for x, u in split), (flag, routes, units)
     assert outs[0].keys() == outs[1].keys() and len(outs[0]) == 10
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), f"{k}: in-kernel merge differs from the combine launch"
