@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64 * NW, (D <= 128 && !(MQ && PG == 1 && D == 128) 
         const int t = k - g * (gp * nmb);
         const int gsize = min(gp, pair_count - g * gp); // pairs in this (possibly last, short) group
         int rank, pi;
-        if (a.interleave_pairs == 3) { // fewer than 8 pairs: no XCD of its own for a pair; query-block-major over all of them
+        if (a.interleave_pairs == 3) { // few pairs, no multiple of 8: no XCD of its own for a pair; query-block-major over all of them
             rank = blockIdx.x / npairs;
             pi = blockIdx.x - rank * npairs;
             g = 0;
@@ -652,9 +652,10 @@ static int launch_prefill_p(PrefillArgs& a, hipStream_t stream) {
     a.group_pairs = knob_gp > 0 ? knob_gp : 4;
     // every XCD gets ceil(npairs / 8) pairs' worth of slots, rounded up to whole groups; surplus blocks exit
     // (lengths differ by batch element: pairs dealt round-robin over the XCDs, see the kernel)
-    // fewer than 8 pairs (one long prompt on a tensor-parallel shard's few heads): an XCD per pair would leave XCDs idle; the
-    // row blocks of all pairs go out in plain order instead (3)
-    a.interleave_pairs = npairs < 8 ? 3 : !(a.cu_q || a.seqlens_k) ? 0 : (int64_t)a.batch * a.kv_heads >= 16 ? 2 : 1;
+    // fewer than 8 pairs (one long prompt on a tensor-parallel shard's few heads): an XCD per pair would leave XCDs idle; a small
+    // pair count that is no multiple of 8 would load them unevenly (12 pairs: four XCDs with two, four with one).  The row
+    // blocks of all pairs go out in plain order instead (3)
+    a.interleave_pairs = npairs < 64 && (npairs & 7) ? 3 : !(a.cu_q || a.seqlens_k) ? 0 : (int64_t)a.batch * a.kv_heads >= 16 ? 2 : 1;
     const int64_t per_xcd = a.interleave_pairs == 2 ? (((int64_t)a.batch * a.kv_heads + 7) / 8) * a.group : (npairs + 7) / 8;
     const int64_t groups = (per_xcd + a.group_pairs - 1) / a.group_pairs;
     const int64_t total = a.interleave_pairs == 3 ? npairs * a.num_m_blocks : 8 * groups * a.group_pairs * a.num_m_blocks;

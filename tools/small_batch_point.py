@@ -16,7 +16,7 @@ if os.environ.get("SMALL_CHILD") != "1":
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mini-flash-attention_amd"))
 import mini_flash_attention as mfa
-for B, H, Hk, S in ((1, 4, 4, 4096), (1, 4, 1, 16384), (1, 6, 2, 8192), (1, 8, 8, 2048), (1, 8, 8, 4096), (1, 8, 8, 8192), (1, 32, 8, 2048), (1, 32, 8, 4096), (1, 32, 8, 8192), (1, 32, 8, 16384),
+for B, H, Hk, S in ((1, 12, 12, 8192), (1, 20, 4, 4096), (1, 28, 4, 8192), (3, 12, 4, 2048), (1, 40, 8, 8192), (1, 4, 4, 4096), (1, 4, 1, 16384), (1, 6, 2, 8192), (1, 8, 8, 2048), (1, 8, 8, 4096), (1, 8, 8, 8192), (1, 32, 8, 2048), (1, 32, 8, 4096), (1, 32, 8, 8192), (1, 32, 8, 16384),
                     (2, 32, 8, 2048), (4, 32, 8, 2048), (1, 64, 8, 4096), (8, 8, 8, 1024), (4, 16, 16, 1024), (2, 24, 8, 1024), (8, 24, 8, 1024)):
     q = torch.randn(B, S, H, 128, device="cuda", dtype=torch.float16)
     k, v = (torch.randn(B, S, Hk, 128, device="cuda", dtype=torch.float16) for _ in range(2))
