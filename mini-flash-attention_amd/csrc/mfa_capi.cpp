@@ -158,7 +158,9 @@ int mfa_device_cu_count(int device) {
 // with well under one workgroup per CU.  Measured on MI355X (tools/split_sweep.py, profiles/r01c_sweep.txt) the time
 // follows workgroup QUANTISATION over the CUs, not occupancy: W = B*Hkv*splits workgroups run at
 //   eff(W) = min(1, W / (3/4 CUs))         for W <= CUs   (192 workgroups on 256 CUs already reach 6.1 TB/s)
-//          = (W / CUs) / ceil(W / CUs)      for W  > CUs   (384 = 1.5/CU is 10 % slower than 192 or 768)
+//          = 1 - (1 - (W / CUs) / ceil(W / CUs)) / 2   for W > CUs: a CU takes a second workgroup beside the first, so a part-filled
+//            last round costs about half of what whole rounds would say (384 = 1.5/CU is 10 % slower than 192 or 768; round 3,
+//            tools/mha_split_sweep.py, 576 rows = 2.25/CU unsplit: Skv 512 29.9 us for 25 us of streaming, Skv 2048 108 for 101)
 // and splitting costs the combine launch (~4 us) plus ~0.15 us per split of partials.  With the streaming time
 // estimated as K+V bytes / 6 TB/s (head_dim 128 assumed) the count minimising  t_stream / eff + t_combine  is
 // taken, never below 4 tiles of 64 keys per split, evened out.  Only the ARGUMENT semantics are the reference's:
@@ -185,7 +187,7 @@ int mfa_num_splits_heuristic(int requested, int batch, int kv_heads, int seqlen_
         if ((ntiles + per - 1) / per != s) continue; // not an even split: the evened count is evaluated on its own
         const double w = base * s;
         const double eff = w <= num_cus ? (w / (0.75 * num_cus) < 1.0 ? w / (0.75 * num_cus) : 1.0)
-                                        : (w / num_cus) / std::ceil(w / num_cus);
+                                        : 1.0 - 0.5 * (1.0 - (w / num_cus) / std::ceil(w / num_cus));
         const double t_stream_us = base * seqlen_k * 512.0 / 6.0e6;
         const double cost = t_stream_us / eff + (s > 1 ? 4.0 + 0.15 * s : 0.0);
         if (cost < best_cost - 1e-9) {
