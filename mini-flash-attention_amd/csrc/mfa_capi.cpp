@@ -248,6 +248,17 @@ static int kvcache_route(const mfa_forward_params* p) {
     const int ps = p->page_block_size;
     const bool paged_group = p->block_table != nullptr && g >= 3 && ps >= 64 && (ps & (ps - 1)) == 0;
     bool packed = has_packed && rows <= 512 && (p->seqlen_q > 1 || g > 4 || p->use_local_window || paged_group);
+    // A long query block on few heads over a long cache (a prompt chunk on a tensor-parallel shard's one KV head): the per-head
+    // prefill kernel has batch * heads * ceil(Sq / 128) workgroups and no way to split the keys; with at most one for every
+    // second CU the packed kernel takes it, whose key splits fill the chip (bf16 B1 Hq8 Hkv1 Sq2048 Skv32768: 541 -> 283 us;
+    // with more workgroups than that the per-head kernel is the faster one, tools/chunked_prefill_point.py)
+    if (!packed && has_packed && p->seqlen_q > 1 && p->seqlen_k >= 4096) {
+        const int cus = p->num_cus > 0 ? p->num_cus : 256;
+        const int64_t wgs = static_cast<int64_t>(p->batch) * p->heads * ((p->seqlen_q + 127) / 128);
+        const int64_t span = static_cast<int64_t>(p->seqlen_q) * std::max(p->q_row_stride, p->o_row_stride) +
+                             static_cast<int64_t>(g) * std::max(p->q_head_stride, p->o_head_stride);
+        packed = 2 * wgs <= cus && span < (1LL << 31);
+    }
     if (env == 0) packed = false;
     if (env == 1 && has_packed) packed = true;
     if (packed) return kKvPacked;

@@ -164,3 +164,18 @@ def test_strided_queries_and_caches(mfa):
     ours = mfa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=lens, causal=True)
     theirs = fa.flash_attn_with_kvcache(q.contiguous(), kc.contiguous(), vc.contiguous(), cache_seqlens=lens, causal=True)
     close(ours, theirs, "strided q / cache")
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_long_query_block_on_few_heads_takes_the_packed_kernel(mfa, capi, causal):
+    """A prompt chunk on one or two KV heads over a long cache: the per-head prefill kernel would have too few workgroups
+    for the chip and cannot split the keys, so the route goes to the packed kernel (thousands of packed rows, many row blocks,
+    key splits) -- values and LSE against the comparator, per-batch cache lengths included."""
+    lib = capi.load()
+    for B, Sq, Hq, Hk, Sk, lens in ((1, 1500, 8, 1, 4500, [4500]), (2, 700, 4, 2, 5000, [4800, 3000]), (1, 1000, 4, 4, 4100, [4100])):
+        q, kc, vc = rnd(B, Sq, Hq, 128, dtype=torch.bfloat16, seed=1), rnd(B, Sk, Hk, 128, dtype=torch.bfloat16, seed=2), rnd(B, Sk, Hk, 128, dtype=torch.bfloat16, seed=3)
+        cl = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        ours, lse = mfa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cl, causal=causal, return_softmax_lse=True)
+        assert lib.mfa_debug_last_route() & capi.MFA_ROUTE_PACKED, (B, Sq, Hq, Hk)
+        theirs, lse_ref = fa.flash_attn_with_kvcache(q, kc, vc, cache_seqlens=cl, causal=causal, return_softmax_lse=True)
+        close(ours, theirs, f"B{B} Sq{Sq} {Hq}/{Hk} causal={causal}", lse.view_as(lse_ref), lse_ref)
