@@ -102,3 +102,55 @@ def test_fuzz_kvcache(mfa, seed):
     kp, vp, table = hp.make_paged(kc, vc, page, seed=seed)
     ours_p = mfa.flash_attn_with_kvcache(q, kp, vp, block_table=table, num_splits=splits, **kw)
     close(ours_p, theirs, what + f" paged({page})")
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_long_sequence_prefill_d128(mfa, capi, seed):
+    """Head dim 128 with sequences long enough for the launcher's choices of round 3 to matter: even and ragged packed batches
+    (static, dealt and length-sorted schedules of the 64-row kernel; the general kernel's pair mappings), any head counts
+    (multiples of 8 and not), 1 .. 70 sequences (more than 64: the general kernel), optionally over a paged cache, and the same
+    shapes as dense batches with few (batch, head) pairs.  Values against the comparator, per sequence."""
+    rng = random.Random(3000 + seed)
+    torch.manual_seed(seed)
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    hk = rng.choice([1, 2, 3, 4, 8])
+    hq = hk * rng.choice([1, 2, 3, 4, 8])
+    causal = rng.random() < 0.6
+    kind = rng.choice(["even", "ragged", "one_long", "many", "dense"])
+    if kind == "dense":
+        B, S = rng.randint(1, 3), rng.choice([384, 512, 700, 1024, 1500, 2048])
+        q, k, v = (torch.randn(B, S, h, 128, device=DEV).to(dtype) for h in (hq, hk, hk))
+        ours, lse = mfa.flash_attn_func(q, k, v, causal=causal, return_softmax_lse=True)
+        theirs, lse_ref, _ = fa.flash_attn_func(q, k, v, causal=causal, return_attn_probs=True)
+        close(ours, theirs, f"dense seed={seed} B{B} S{S} {hq}/{hk} causal={causal} route={capi.load().mfa_debug_last_route()}", lse, lse_ref)
+        return
+    if kind == "even":
+        base = rng.choice([512, 640, 1024, 1536])
+        lens = [base - rng.randint(0, base // 12) for _ in range(rng.randint(2, 12))]
+    elif kind == "ragged":
+        lens = [rng.randint(1, 3000) for _ in range(rng.randint(2, 16))]
+    elif kind == "one_long":
+        lens = [rng.choice([2048, 3000, 4096])] + [rng.randint(0, 300) for _ in range(rng.randint(1, 20))]
+        rng.shuffle(lens)
+    else:
+        lens = [rng.choice([0, 64, 200, 513, 600, 900]) for _ in range(rng.randint(65, 70))]
+        lens[rng.randrange(len(lens))] = 1200
+    while sum(lens) > 24000:
+        lens.pop()
+    cu = torch.tensor([0] + lens, device=DEV, dtype=torch.int32).cumsum(0, dtype=torch.int32)
+    q = torch.randn(sum(lens), hq, 128, device=DEV).to(dtype)
+    k, v = (torch.randn(sum(lens), hk, 128, device=DEV).to(dtype) for _ in range(2))
+    ours, lse = mfa.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=causal, return_softmax_lse=True)
+    route = capi.load().mfa_debug_last_route()
+    theirs, lse_ref, _ = fa.flash_attn_varlen_func(q, k, v, cu, cu, max(lens), max(lens), causal=causal, return_attn_probs=True)
+    what = f"varlen seed={seed} {kind} n={len(lens)} max={max(lens)} {hq}/{hk} {dtype} causal={causal} route={route}"
+    close(ours, theirs, what, lse, lse_ref)
+    if rng.random() < 0.6:  # the same batch over a paged cache (sequence i's keys in the pages of table row i)
+        page = rng.choice([16, 64, 128, 256])
+        smax = max(lens)
+        kd, vd = torch.zeros(len(lens), smax, hk, 128, device=DEV, dtype=dtype), torch.zeros(len(lens), smax, hk, 128, device=DEV, dtype=dtype)
+        for i, n in enumerate(lens):
+            kd[i, :n], vd[i, :n] = k[int(cu[i]):int(cu[i]) + n], v[int(cu[i]):int(cu[i]) + n]
+        kp, vp, table = hp.make_paged(kd, vd, page, seed=seed)
+        ours_p = mfa.flash_attn_varlen_func(q, kp, vp, cu, cu, smax, smax, causal=causal, block_table=table)
+        close(ours_p, theirs, what + f" paged({page}) route={capi.load().mfa_debug_last_route()}")

@@ -45,10 +45,11 @@ def test_bit_determinism():
 
 
 def test_prefill_suite_with_the_64_row_kernel_forced():
-    """The parity suite of the prefill entry once more in a child with MFA_PREFILL64=2: every shape the 64-row kernel accepts
+    """The parity suite of the prefill entry and the long-sequence fuzz once more in a child with MFA_PREFILL64=2: every shape the 64-row kernel accepts
     (dense below the routing threshold, ragged varlen batches, paged K/V with pages >= 64 keys) goes to it instead of the
     general kernel the launcher would pick (the tests that pin the launcher's own choice skip that assertion)."""
     env = dict(os.environ, MFA_PREFILL64="2", MFA_PARITY_RECORD="parity_r03_forced64.json")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_prefill_gpu.py"), "-q", "-x", "-p", "no:cacheprovider"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_prefill_gpu.py"),
+                        os.path.join(ROOT, "tests", "test_fuzz_gpu.py") + "::test_fuzz_long_sequence_prefill_d128", "-q", "-x", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout + r.stderr)[-2000:]
