@@ -744,12 +744,12 @@ int launch_prefill(const mfa_forward_params& p, hipStream_t stream, bool* used_p
     if (a.cu_q) {
         const bool even = a.batch > 0 && 10 * a.total_q >= 9 * (int64_t)a.batch * a.seqlen_q;
         a.p64_ragged = !even;
-        // ragged: the length-sorted schedule (at most 64 sequences of at most 64 row blocks) where long sequences carry the
+        // ragged: the schedule built from the lengths (at most 256 sequences of at most 64 row blocks) where long sequences carry the
         // work -- a mean length of 512, or a longest sequence that outweighs the rest even if the rest were all 256 long
         // (the general kernel is the faster one on sequences that short)
         const int64_t rest = a.total_q - a.seqlen_q;
         const bool long_heavy = a.total_q >= 512 * (int64_t)a.batch || (int64_t)a.seqlen_q * a.seqlen_q >= 256 * rest;
-        p64_fits = p64_fits && a.seqlen_q >= p64_from && (even || (a.batch <= 64 && a.seqlen_q <= 64 * 256 && long_heavy));
+        p64_fits = p64_fits && a.seqlen_q >= p64_from && (even || (a.batch <= 256 && a.seqlen_q <= 64 * 256 && long_heavy));
     }
     if (env_p64 == 2 || (env_p64 == 1 && p64_fits)) {
         a.p64_forced = env_p64 == 2;

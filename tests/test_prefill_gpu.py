@@ -181,7 +181,8 @@ def test_varlen_ragged_long_batches(mfa, capi, H, Hk):
     lib = capi.load()
     g = torch.Generator().manual_seed(11)
     for lens, want64 in (([4096] + [256] * 9, True), (torch.randint(100, 3001, (12,), generator=g).tolist(), True),
-                         ([2000, 0, 1500, 3, 700], True), ([1024] + [200] * 40, False), ([600, 400], False)):
+                         ([2000, 0, 1500, 3, 700], True), ([1024] + [200] * 40, False), ([600, 400], False),
+                         (torch.randint(300, 1501, (100,), generator=g).tolist(), True), ([1200] + [520] * 199, True)):
         tot = sum(lens)
         cu = torch.tensor([0] + lens).cumsum(0).int().to(DEV)
         q, k, v = rnd(tot, H, 128, dtype=torch.bfloat16, seed=1), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=2), rnd(tot, Hk, 128, dtype=torch.bfloat16, seed=3)
@@ -190,12 +191,22 @@ def test_varlen_ragged_long_batches(mfa, capi, H, Hk):
                 out = hp.prefill(route, mfa, capi, q, k, v, causal, cu_q=cu, cu_k=cu, max_sq=max(lens), max_sk=max(lens))
                 if "MFA_PREFILL64" not in os.environ:  # (the launcher's own choice; a forced-route run skips the check)
                     assert bool(lib.mfa_debug_last_route() & capi.MFA_ROUTE_PREFILL64) == want64, (lens[:4], route)
-                for i, n in enumerate(lens):
+                # (more than 16 sequences: a seeded sample of them -- each also as a batch of one, which the schedule must
+                #  reproduce bit for bit)
+                picks = range(len(lens)) if len(lens) <= 16 else sorted(torch.randperm(len(lens), generator=g)[:12].tolist())
+                for i in picks:
+                    n = lens[i]
                     if n == 0:
                         continue
                     s0 = int(cu[i])
                     ref = hp.sdpa_gpu(q[s0:s0 + n][None], k[s0:s0 + n][None], v[s0:s0 + n][None], causal)[0]
                     assert_close(out[s0:s0 + n], ref, p_rounded=True, what=f"ragged {lens[:4]} seq {i} {route} causal={causal}")
+                    if len(lens) > 16 and route == "api":
+                        c1 = torch.tensor([0, n], dtype=torch.int32, device=DEV)
+                        alone = mfa.flash_attn_varlen_func(q[s0:s0 + n], k[s0:s0 + n], v[s0:s0 + n], c1, c1, n, n, causal=causal)
+                        lone64 = bool(lib.mfa_debug_last_route() & capi.MFA_ROUTE_PREFILL64)
+                        if lone64 == want64:  # (same kernel on both sides: the same arithmetic in the same order)
+                            assert torch.equal(alone, out[s0:s0 + n]), f"ragged seq {i}: differs from the batch of one"
 
 
 def test_varlen_different_q_and_k_lengths(mfa, capi, oracle):

@@ -31,6 +31,8 @@ cases = {
     "512..4096 x 16": torch.randint(512, 4097, (16,), generator=g).tolist(),
     "128..4096 log x 32": (128 * 2 ** (5 * torch.rand(32, generator=g))).int().tolist(),
     "one 8192 + 31 x 256": [8192] + [256] * 31,
+    "300..1500 x 100": torch.randint(300, 1501, (100,), generator=g).tolist(),
+    "200 x 512..1024": torch.randint(512, 1025, (200,), generator=g).tolist(),
 }
 for name, lens in cases.items():
     T = sum(lens)
