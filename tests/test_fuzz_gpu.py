@@ -108,7 +108,7 @@ def test_fuzz_kvcache(mfa, seed):
 def test_fuzz_long_sequence_prefill_d128(mfa, capi, seed):
     """Head dim 128 with sequences long enough for the launcher's choices of round 3 to matter: even and ragged packed batches
     (static, dealt and length-sorted schedules of the 64-row kernel; the general kernel's pair mappings), any head counts
-    (multiples of 8 and not), 1 .. 70 sequences (more than 64: the general kernel), optionally over a paged cache, and the same
+    (multiples of 8 and not), 1 .. 70 sequences (more than 64: a second register of the schedule's tables), optionally over a paged cache, and the same
     shapes as dense batches with few (batch, head) pairs.  Values against the comparator, per sequence."""
     rng = random.Random(3000 + seed)
     torch.manual_seed(seed)
